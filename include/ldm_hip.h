@@ -1,0 +1,172 @@
+/*
+ * ldm_hip.h -- C ABI of the MI355X (gfx950) latent-diffusion hot path.
+ *
+ * The reference (uthree/ldm-image-generator) has no FFI/plugin layer: its hot
+ * path is PyTorch ATen ops issued from unet.py / attention.py / modules.py /
+ * sinusoidal.py / vae.py / ddpm.py.  This header is the boundary a maintainer
+ * binds instead of those ATen calls (ctypes stub in INTEGRATION.md).  Each entry
+ * point names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers to fp32
+ *     unless stated; the caller (PyTorch) owns every buffer, incl. workspaces;
+ *   - activations are channels-last: [B, H, W, C] == [M = B*H*W rows, C cols];
+ *     the NCHW tensors of the reference cross the boundary only in
+ *     ldm_stem_nchw_f32 / ldm_head_nchw_f32 / ldm_rgb_head_f32 / ldm_nchw_to_nhwc_f32;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) and is re-entrant; safe under hipGraph capture;
+ *   - return 0 on success, a negative LDM_E* code otherwise (never throws);
+ *     ldm_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef LDM_HIP_H
+#define LDM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDM_OK          0
+#define LDM_EINVAL     -1   /* bad shape / alignment / null pointer            */
+#define LDM_ELAUNCH    -2   /* hipLaunch / runtime error (see ldm_last_error)  */
+#define LDM_ENODEV     -3   /* no gfx950 device                                */
+
+#define LDM_MAX_SEG     4
+
+/* epilogue activation of ldm_gemm_f32 */
+#define LDM_ACT_NONE    0
+#define LDM_ACT_RELU    1   /* unet.py:13,20 (Encodings.act)                   */
+#define LDM_ACT_GATE    2   /* modules.py:15  a(x) * relu(b(x))                */
+#define LDM_ACT_LRELU   3   /* vae.py:62,64   F.leaky_relu (slope in desc)     */
+
+/* A-operand addressing */
+#define LDM_A_ROWS      0   /* row m at a + m*lda (1x1 conv / Linear)          */
+#define LDM_A_CONV3X3   1   /* implicit im2col, zero pad 1 (vae.py:57-58, unet.py:30) */
+
+/* output addressing */
+#define LDM_O_ROWS      0   /* out[m*ldo + n]                                  */
+#define LDM_O_CONVT2X2  1   /* ConvTranspose2d(k=2,s=2) scatter (vae.py:120)   */
+#define LDM_O_UP2       2   /* nearest x2 replicate (+addend at the fine grid) (unet.py:85,101) */
+
+/* which segment dimension the weight pointers split */
+#define LDM_SEG_N       0   /* w[s] holds rows [s*seg_len, (s+1)*seg_len) of the N axis */
+#define LDM_SEG_K       1   /* w[s] holds K-columns [s*seg_len, ...) for all N rows      */
+
+/*
+ * One fp32 GEMM launch on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *
+ *     out = act(A . W^T + bias) (+ addend)
+ *
+ * A is [M, K] (rows or implicit 3x3 im2col), every weight segment is a
+ * row-major [rows, K-columns] matrix with row stride ldw (i.e. the reference's
+ * Conv2d / Linear weight as stored in its state_dict, K contiguous).
+ * Used for: ReGLU/RandomMoE (modules.py:14-15,34-36, weights selected by
+ * pointer, never copied), Encodings MLP (unet.py:20), MHA in/out projections
+ * (attention.py:82 -> torch multi_head_attention_forward), the 1x1 ch_convs
+ * (unet.py:83,85), grouped 3x3 conv (unet.py:30,44; groups on grid.y), the VAE
+ * dense 3x3 convs, ConvTranspose2d 2x2 and input_layer (vae.py:57-58,103,120).
+ */
+typedef struct ldm_gemm_desc {
+    const float *a;          /* A operand                                        */
+    long long    lda;        /* row stride of A in floats (LDM_A_ROWS) / pixel stride (CONV3X3) */
+    int          M, N, K;    /* K = Cin (ROWS) or 9*Cin (CONV3X3); N, K%32 == 0  */
+    int          a_mode;     /* LDM_A_*                                          */
+    int          H, W, Cin;  /* CONV3X3: spatial dims of A, M == B*H*W           */
+
+    int          nseg;       /* 1..LDM_MAX_SEG weight segments                   */
+    int          seg_mode;   /* LDM_SEG_*                                        */
+    int          seg_len;    /* extent of one segment along its axis             */
+    const float *w[LDM_MAX_SEG];     /* weight segments                          */
+    const float *w2[LDM_MAX_SEG];    /* LDM_ACT_GATE: the "b" weights            */
+    const float *bias[LDM_MAX_SEG];  /* may be NULL                              */
+    const float *bias2[LDM_MAX_SEG]; /* LDM_ACT_GATE: the "b" biases             */
+    long long    ldw;        /* weight row stride in floats                      */
+
+    int          act;        /* LDM_ACT_*                                        */
+    float        slope;      /* LDM_ACT_LRELU                                    */
+
+    const float *addend;     /* optional, same addressing as out                 */
+    long long    ldadd;
+    float       *out;
+    long long    ldo;
+    int          o_mode;     /* LDM_O_*                                          */
+    int          OH, OW;     /* CONVT2X2 / UP2: coarse grid, M == B*OH*OW        */
+    int          Cout;       /* CONVT2X2: N == 4*Cout, n = (dy*2+dx)*Cout + co   */
+
+    int          groups;     /* >=1; grouped conv: per-group offsets below       */
+    long long    a_gstride;  /* floats added to the A column offset per group    */
+    long long    w_gstride;  /* floats added to every w[s] per group             */
+    long long    o_gstride;  /* floats added to out/addend/bias column per group */
+} ldm_gemm_desc;
+
+int         ldm_version(void);
+const char *ldm_last_error(void);
+int         ldm_device_ok(void);          /* 1 if device 0 is gfx950 */
+
+int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
+
+/* hot-kernel timing for bench.py: when enabled every ldm_gemm_f32 launch is
+ * bracketed by hipEvents on ITS stream; ldm_prof_read synchronises those events
+ * and returns launches, summed kernel milliseconds and summed algorithmic FLOPs. */
+int ldm_prof_enable(int on);
+int ldm_prof_read(long long *launches, double *ms, double *flops);
+
+/* modules.py:23-25 (ChannelNorm, unbiased var, eps inside sqrt) fused with the
+ * FiLM of unet.py:22.  film is [nslot, HW, 2C] (mul | bias); slot[b] selects the
+ * time slot of sample b (NULL: slot 0 for everyone). */
+int ldm_channelnorm_film_f32(const float *x, const float *film, const int *slot, float *out,
+                             int B, int HW, int C, float eps, void *stream);
+/* unet.py:22 alone: out = x * mul + bias (Encodings.forward without the norm). */
+int ldm_film_f32(const float *x, const float *film, const int *slot, float *out, int B, int HW, int C, void *stream);
+
+/* sinusoidal.py:12-19,31-38 + the cat of unet.py:19: writes emb[nT, H*W, 2C] =
+ * cat[PositionalEncoding2d(h,w), TimeEncoding2d(t)].  pos_freq[C/4] and
+ * time_freq[C/2] are the reference's frequency tables (host-computed). */
+int ldm_sincos_embed_f32(const long long *t, int nT, int H, int W, int C,
+                         const float *pos_freq, const float *time_freq, float *emb, void *stream);
+
+/* attention.py:13-85 core (pad, roll, window split, per-head softmax(q k^T/sqrt(d) + mask) v,
+ * un-roll, crop).  qkv [B,H,W,3C] is the packed in-projection of the UNPADDED
+ * tokens; padded tokens are synthesised from in_proj_bias.  shift==0 uses the
+ * boolean padding mask; shift!=0 reproduces attention.py:40's float "mask"
+ * (channel 0 of the twice-rolled input xf) as an additive key bias.  If
+ * H<=ws && W<=ws attention is global and unmasked (attention.py:15-16). */
+int ldm_window_attention_f32(const float *qkv, const float *in_proj_bias, const float *xf, float *out,
+                             int B, int H, int W, int C, int ws, int shift, void *stream);
+
+/* nn.AvgPool2d(2) on [B,H,W,C] (unet.py:83; commuted in front of the 1x1 conv). */
+int ldm_avgpool2_f32(const float *x, float *out, int B, int H, int W, int C, void *stream);
+
+/* unet.py:77,90  stem Conv2d(Cin, C0, 1): NCHW in -> NHWC out.  w [C0, Cin]. */
+int ldm_stem_nchw_f32(const float *x, const float *w, const float *bias, float *out,
+                      int B, int Cin, int HW, int C0, void *stream);
+/* unet.py:78,102 head ConvTranspose2d(C0, Cin, 1): NHWC in -> NCHW out.  w [C0, Cin]. */
+int ldm_head_nchw_f32(const float *x, const float *w, const float *bias, float *out,
+                      int B, int C0, int HW, int Cin, void *stream);
+
+/* ddpm.py:81-91 one DDIM update, elementwise, in place on x:
+ *   x0 = (x - s1*e)/s2 ;  x = last ? x0 : s3*x0 + s4*e + sigma*noise
+ * (each product and sum rounded separately, as torch evaluates it). noise may be NULL when sigma == 0. */
+int ldm_ddim_update_f32(float *x, const float *e_theta, const float *noise, long long n,
+                        float s1, float s2, float s3, float s4, float sigma, int last, void *stream);
+
+/* ddpm.py:46 q-sample: out = sqrt(ab[b])*x + sqrt(1-ab[b])*e, per-sample scalars precomputed by the host. */
+int ldm_qsample_f32(const float *x, const float *e, const float *sa, const float *sb, float *out,
+                    int B, long long per_sample, void *stream);
+
+/* vae.py:105,113,131: rgb = to_rgb(x) (1x1, C->3) and
+ * out = bilinear_x2(prev) + rgb  (prev NULL: out = rgb).  x is NHWC [B,H,W,C];
+ * prev [B,3,H/2,W/2] and out [B,3,H,W] are NCHW like the reference's result. */
+int ldm_rgb_head_f32(const float *x, const float *w, const float *bias, const float *prev, float *out,
+                     int B, int H, int W, int C, void *stream);
+
+/* layout plumbing at the boundary */
+int ldm_nchw_to_nhwc_f32(const float *x, float *out, int B, int C, int HW, void *stream);
+int ldm_nhwc_to_nchw_f32(const float *x, float *out, int B, int C, int HW, void *stream);
+
+/* sample_ldm.py:75-77: clamp(-1,1) -> *127.5+127.5 -> uint8 truncation, NCHW -> NHWC bytes. */
+int ldm_to_uint8_hwc(const float *img, unsigned char *out, int B, int C, int HW, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI library (include/ldm_hip.h).
+
+The product path has NO fallback: if ``libldm_hip.so`` is missing or cannot be
+loaded, every op raises ``LdmHipUnavailable`` (importing the package itself stays
+possible on a CPU-only box so that host logic and symbol checks can be tested).
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libldm_hip.so")
+
+LDM_MAX_SEG = 4
+ACT_NONE, ACT_RELU, ACT_GATE, ACT_LRELU = 0, 1, 2, 3
+A_ROWS, A_CONV3X3 = 0, 1
+O_ROWS, O_CONVT2X2, O_UP2 = 0, 1, 2
+SEG_N, SEG_K = 0, 1
+
+c_fp = ctypes.c_void_p      # device pointers travel as plain addresses
+
+
+class LdmHipUnavailable(RuntimeError):
+    pass
+
+
+class LdmHipError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    """struct ldm_gemm_desc (include/ldm_hip.h) -- field order must match."""
+    _fields_ = [
+        ("a", c_fp), ("lda", ctypes.c_longlong),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("a_mode", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int),
+        ("nseg", ctypes.c_int), ("seg_mode", ctypes.c_int), ("seg_len", ctypes.c_int),
+        ("w", c_fp * LDM_MAX_SEG), ("w2", c_fp * LDM_MAX_SEG),
+        ("bias", c_fp * LDM_MAX_SEG), ("bias2", c_fp * LDM_MAX_SEG),
+        ("ldw", ctypes.c_longlong),
+        ("act", ctypes.c_int), ("slope", ctypes.c_float),
+        ("addend", c_fp), ("ldadd", ctypes.c_longlong),
+        ("out", c_fp), ("ldo", ctypes.c_longlong),
+        ("o_mode", ctypes.c_int), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("Cout", ctypes.c_int),
+        ("groups", ctypes.c_int),
+        ("a_gstride", ctypes.c_longlong), ("w_gstride", ctypes.c_longlong), ("o_gstride", ctypes.c_longlong),
+    ]
+
+
+_I, _L, _F, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/ldm_hip.h
+SIGNATURES = {
+    "ldm_version": (_I, []),
+    "ldm_last_error": (ctypes.c_char_p, []),
+    "ldm_device_ok": (_I, []),
+    "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
+    "ldm_prof_enable": (_I, [_I]),
+    "ldm_prof_read": (_I, [ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ldm_channelnorm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ldm_sincos_embed_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ldm_window_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_avgpool2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_stem_nchw_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_head_nchw_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_ddim_update_f32": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "ldm_qsample_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
+    "ldm_rgb_head_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ldm_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ldm_to_uint8_hwc": (_I, [_P, _P, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdmHipUnavailable(
+            "%s is missing: build it with `python -m ldm_image_generator_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:          # e.g. libamdhip64 not present
+        raise LdmHipUnavailable("cannot load %s: %s" % (LIB_PATH, exc))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here == ABI mismatch, let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().ldm_last_error()
+        raise LdmHipError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))

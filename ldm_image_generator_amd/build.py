@@ -1,0 +1,43 @@
+"""Build recipe for the C-ABI HIP library (libldm_hip.so), gfx950 only.
+
+hipcc cross-compiles without a GPU, so this runs in the build container and on
+the GPU box alike.  The library is built IN-TREE (next to this file) so that it
+travels with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libldm_hip.so")
+SOURCES = ["gemm.hip", "elementwise.hip", "attention.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "ldm_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    if verbose:
+        print(res.stdout)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose="-v" in sys.argv)
+    print("built", LIB)

@@ -1,0 +1,458 @@
+// HBM-bound kernels of the UNet / VAE / DDIM path: coalesced 16-B accesses,
+// wave-shuffle reductions, no LDS except for the two layout transposes.
+#include "common.h"
+#include <cmath>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void ldm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ldm_last_error(void) { return g_err; }
+extern "C" int ldm_version(void) { return 100; }
+
+extern "C" int ldm_device_ok(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+namespace {
+
+constexpr int kMaxV = 8;   // float4 per lane per row -> C <= 2048
+
+__device__ __forceinline__ float group_sum(float v, int lpr)
+{
+    for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// ChannelNorm + FiLM: one row (pixel) per group of `lpr` lanes
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channelnorm_film_kernel(const float *__restrict__ x, const float *__restrict__ film,
+                                                               const int *__restrict__ slot, float *__restrict__ out,
+                                                               long long rows, int HW, int C, float eps, int lpr, int normalize)
+{
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long row = wave * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const int c4n = C >> 2;
+    const bool live = row < rows;
+    const f32x4 *xr = (const f32x4 *)(x + (live ? row : 0) * C);
+    f32x4 v[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        v[i] = (live && c4 < c4n) ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = group_sum(s, lpr) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    const float var = group_sum(ss, lpr) / (float)(C - 1);     // unbiased, modules.py:24
+    const float den = sqrtf(var + eps);
+    if (!live) return;
+    const float mean_ = normalize ? mean : 0.f;
+    const int b = (int)(row / HW), pix = (int)(row - (long long)b * HW);
+    const int sl = slot ? slot[b] : 0;
+    const f32x4 *fr = (const f32x4 *)(film + ((long long)sl * HW + pix) * 2 * C);
+    f32x4 *orow = (f32x4 *)(out + row * C);
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+            const f32x4 mu = fr[c4], bi = fr[c4n + c4];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xn = normalize ? (v[i][e] - mean_) / den : v[i][e];
+                o[e] = __fadd_rn(__fmul_rn(xn, mu[e]), bi[e]);
+            }
+            orow[c4] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sin/cos position + time codes, emb[nT, HW, 2C]
+// ---------------------------------------------------------------------------
+__global__ void sincos_embed_kernel(const long long *__restrict__ t, int nT, int H, int W, int C,
+                                    const float *__restrict__ pf, const float *__restrict__ tf, float *__restrict__ emb)
+{
+    const long long total = (long long)nT * H * W * 2 * C;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % (2 * C));
+    const long long rowi = idx / (2 * C);
+    const int pix = (int)(rowi % (H * W));
+    const int ti = (int)(rowi / (H * W));
+    const float pi = 3.14159265358979323846f;
+    float val;
+    if (c < C) {
+        const int q = C >> 2;
+        const int k = c % q, kind = c / q;            // 0 sin(row) 1 cos(row) 2 sin(col) 3 cos(col)
+        const int y = pix / W, xx = pix - y * W;
+        const float pos = (kind < 2) ? (float)y / (float)H : (float)xx / (float)W;   // sinusoidal.py:13-14
+        const float arg = __fmul_rn(__fmul_rn(pos, pi), pf[k]);                       // (ev * pi) * f
+        val = (kind & 1) ? cosf(arg) : sinf(arg);
+    } else {
+        const int cc = c - C, half = C >> 1;
+        const int k = cc % half;
+        const float arg = __fmul_rn(__fmul_rn((float)t[ti], pi), tf[k]);              // sinusoidal.py:36-37
+        val = (cc >= half) ? cosf(arg) : sinf(arg);
+    }
+    emb[idx] = val;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void avgpool2_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__ out, int B, int H, int W, int c4n)
+{
+    const int OH = H >> 1, OW = W >> 1;
+    const long long total = (long long)B * OH * OW * c4n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % c4n);
+    long long r = idx / c4n;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const long long b = r / OH;
+    const f32x4 *p = x + ((b * H + 2 * oy) * W + 2 * ox) * c4n + c4;
+    const f32x4 a = p[0], bq = p[c4n], c = p[(long long)W * c4n], d = p[(long long)W * c4n + c4n];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (((a[e] + bq[e]) + c[e]) + d[e]) * 0.25f;
+    out[idx] = o;
+}
+
+// stem: NCHW -> NHWC, 1x1 conv with tiny K
+__global__ void stem_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                            float *__restrict__ out, long long M, int Cin, int HW, int C0)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * C0) return;
+    const int n = (int)(idx % C0);
+    const long long m = idx / C0;
+    const long long b = m / HW;
+    const int pix = (int)(m - b * HW);
+    float acc = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) acc = fmaf(x[(b * Cin + ci) * HW + pix], w[n * Cin + ci], acc);
+    out[idx] = acc + (bias ? bias[n] : 0.f);
+}
+
+// head: NHWC -> NCHW, ConvTranspose 1x1 (w [C0, Cin]); 64 pixels per block, C0 walked in chunks of 128
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ out, long long M,
+                                                   int C0, int HW, int Cin)
+{
+    __shared__ float tile[64 * 129];
+    const int t = threadIdx.x, p = t & 63, cg = t >> 6;
+    const long long m0 = (long long)blockIdx.x * 64;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};          // outputs cg, cg+4, cg+8, cg+12  (Cin <= 16)
+    for (int c0 = 0; c0 < C0; c0 += 128) {
+        const int cw = min(128, C0 - c0);
+        for (int i = t; i < 64 * cw; i += 256) {
+            const int rr = i / cw, cc = i - rr * cw;
+            const long long m = m0 + rr;
+            tile[rr * 129 + cc] = m < M ? x[m * C0 + c0 + cc] : 0.f;
+        }
+        __syncthreads();
+        for (int c = 0; c < cw; ++c) {
+            const float xv = tile[p * 129 + c];
+            const float *wr = w + (long long)(c0 + c) * Cin;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = cg + 4 * k;
+                if (co < Cin) acc[k] = fmaf(xv, wr[co], acc[k]);
+            }
+        }
+        __syncthreads();
+    }
+    const long long m = m0 + p;
+    if (m >= M) return;
+    const long long b = m / HW;
+    const int pix = (int)(m - b * HW);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = cg + 4 * k;
+        if (co < Cin) out[(b * Cin + co) * HW + pix] = acc[k] + (bias ? bias[co] : 0.f);
+    }
+}
+
+__global__ void ddim_update_kernel(float *__restrict__ x, const float *__restrict__ e, const float *__restrict__ noise,
+                                   long long n, float s1, float s2, float s3, float s4, float sigma, int last)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ev = e[i];
+    const float x0 = __fsub_rn(x[i], __fmul_rn(s1, ev)) / s2;                         // ddpm.py:82
+    float r = x0;
+    if (!last) {
+        r = __fadd_rn(__fmul_rn(s3, x0), __fmul_rn(s4, ev));                          // ddpm.py:83-84,91
+        r = __fadd_rn(r, __fmul_rn(sigma, noise ? noise[i] : 0.f));                   // ddpm.py:85
+    }
+    x[i] = r;
+}
+
+__global__ void qsample_kernel(const float *__restrict__ x, const float *__restrict__ e, const float *__restrict__ sa,
+                               const float *__restrict__ sb, float *__restrict__ out, long long n, long long per)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long b = i / per;
+    out[i] = __fadd_rn(__fmul_rn(sa[b], x[i]), __fmul_rn(sb[b], e[i]));               // ddpm.py:46
+}
+
+// to_rgb (C -> 3) + bilinear x2 accumulation of the previous stage's RGB (NCHW planes)
+__global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, const float *__restrict__ prev,
+                                                       float *__restrict__ out, int B, int H, int W, int C, int lpr)
+{
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const long long rows = (long long)B * H * W;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long row = wave * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const int c4n = C >> 2;
+    const bool live = row < rows;
+    const f32x4 *xr = (const f32x4 *)(x + (live ? row : 0) * C);
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int c4 = sub; c4 < c4n; c4 += lpr) {
+        const f32x4 v = live ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 w0 = ((const f32x4 *)w)[c4], w1 = ((const f32x4 *)(w + C))[c4], w2 = ((const f32x4 *)(w + 2 * C))[c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d0 = fmaf(v[e], w0[e], d0);
+            d1 = fmaf(v[e], w1[e], d1);
+            d2 = fmaf(v[e], w2[e], d2);
+        }
+    }
+    d0 = group_sum(d0, lpr);
+    d1 = group_sum(d1, lpr);
+    d2 = group_sum(d2, lpr);
+    if (!live || sub != 0) return;
+    const int HW = H * W;
+    const long long b = row / HW;
+    const int pix = (int)(row - b * HW);
+    const int y = pix / W, xx = pix - y * W;
+    float r[3] = {d0 + bias[0], d1 + bias[1], d2 + bias[2]};
+    if (prev) {
+        const int PH = H >> 1, PW = W >> 1;
+        // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)  (vae.py:131)
+        float sy = 0.5f * (float)y - 0.25f, sx = 0.5f * (float)xx - 0.25f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < PH - 1 ? 1 : 0), x1 = x0 + (x0 < PW - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float *pp = prev + (b * 3 + j) * PH * PW;
+            const float top = hx * pp[y0 * PW + x0] + lx * pp[y0 * PW + x1];
+            const float bot = hx * pp[y1 * PW + x0] + lx * pp[y1 * PW + x1];
+            r[j] = (hy * top + ly * bot) + r[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[(b * 3 + j) * HW + pix] = r[j];
+}
+
+// [B, R, Cc] -> [B, Cc, R] for any R, Cc (32x32 LDS tiles); used for NCHW <-> NHWC
+__global__ void transpose_kernel(const float *__restrict__ x, float *__restrict__ out, int R, int Cc)
+{
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: ty 0..7
+    for (int i = ty; i < 32; i += 8) {
+        const int rr = r0 + i, cc = c0 + tx;
+        tile[i][tx] = (rr < R && cc < Cc) ? x[(b * R + rr) * Cc + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int cc = c0 + i, rr = r0 + tx;
+        if (rr < R && cc < Cc) out[(b * Cc + cc) * R + rr] = tile[tx][i];
+    }
+}
+
+__global__ void to_uint8_kernel(const float *__restrict__ img, unsigned char *__restrict__ out, int B, int C, int HW)
+{
+    const long long total = (long long)B * C * HW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over the OUTPUT [B, HW, C]
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    const int pix = (int)(r % HW);
+    const long long b = r / HW;
+    float v = img[(b * C + c) * HW + pix];
+    v = fminf(fmaxf(v, -1.f), 1.f);                                              // sample_ldm.py:75
+    v = __fadd_rn(__fmul_rn(v, 127.5f), 127.5f);                                 // sample_ldm.py:77
+    out[idx] = (unsigned char)(int)v;                                            // astype(uint8): truncation
+}
+
+inline int pow2_lanes(int c4n)
+{
+    int lpr = 1;
+    while (lpr < c4n && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int ldm_channelnorm_film_f32(const float *x, const float *film, const int *slot, float *out, int B, int HW, int C,
+                                        float eps, void *stream)
+{
+    LDM_REQUIRE(x && film && out, "ldm_channelnorm_film_f32: null pointer");
+    LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_f32: bad shape B=%d HW=%d C=%d", B, HW, C);
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(film) && ldm_aligned16(out), "ldm_channelnorm_film_f32: unaligned pointer");
+    const int lpr = pow2_lanes(C / 4);
+    const long long rows = (long long)B * HW;
+    const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL(channelnorm_film_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, out, rows, HW, C, eps, lpr, 1);
+    LDM_CHECK_LAUNCH("ldm_channelnorm_film_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_film_f32(const float *x, const float *film, const int *slot, float *out, int B, int HW, int C, void *stream)
+{
+    LDM_REQUIRE(x && film && out, "ldm_film_f32: null pointer");
+    LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_film_f32: bad shape B=%d HW=%d C=%d", B, HW, C);
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(film) && ldm_aligned16(out), "ldm_film_f32: unaligned pointer");
+    const int lpr = pow2_lanes(C / 4);
+    const long long rows = (long long)B * HW;
+    const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL(channelnorm_film_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, out, rows, HW, C, 0.f, lpr, 0);
+    LDM_CHECK_LAUNCH("ldm_film_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_sincos_embed_f32(const long long *t, int nT, int H, int W, int C, const float *pos_freq, const float *time_freq,
+                                    float *emb, void *stream)
+{
+    LDM_REQUIRE(t && pos_freq && time_freq && emb, "ldm_sincos_embed_f32: null pointer");
+    LDM_REQUIRE(nT > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ldm_sincos_embed_f32: bad shape nT=%d H=%d W=%d C=%d", nT, H, W, C);
+    const long long total = (long long)nT * H * W * 2 * C;
+    hipLaunchKernelGGL(sincos_embed_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, t, nT, H, W, C, pos_freq, time_freq, emb);
+    LDM_CHECK_LAUNCH("ldm_sincos_embed_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_avgpool2_f32(const float *x, float *out, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(x && out, "ldm_avgpool2_f32: null pointer");
+    LDM_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "ldm_avgpool2_f32: bad shape %d %d %d %d", B, H, W, C);
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(out), "ldm_avgpool2_f32: unaligned pointer");
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (f32x4 *)out, B, H, W, C / 4);
+    LDM_CHECK_LAUNCH("ldm_avgpool2_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_stem_nchw_f32(const float *x, const float *w, const float *bias, float *out, int B, int Cin, int HW, int C0, void *stream)
+{
+    LDM_REQUIRE(x && w && out, "ldm_stem_nchw_f32: null pointer");
+    LDM_REQUIRE(B > 0 && Cin > 0 && HW > 0 && C0 > 0, "ldm_stem_nchw_f32: bad shape");
+    const long long M = (long long)B * HW;
+    hipLaunchKernelGGL(stem_kernel, dim3(blocks_for(M * C0, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, M, Cin, HW, C0);
+    LDM_CHECK_LAUNCH("ldm_stem_nchw_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_head_nchw_f32(const float *x, const float *w, const float *bias, float *out, int B, int C0, int HW, int Cin, void *stream)
+{
+    LDM_REQUIRE(x && w && out, "ldm_head_nchw_f32: null pointer");
+    LDM_REQUIRE(B > 0 && C0 > 0 && HW > 0 && Cin > 0 && Cin <= 16, "ldm_head_nchw_f32: bad shape (Cin=%d must be <= 16)", Cin);
+    const long long M = (long long)B * HW;
+    hipLaunchKernelGGL(head_kernel, dim3(blocks_for(M, 64)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, M, C0, HW, Cin);
+    LDM_CHECK_LAUNCH("ldm_head_nchw_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_ddim_update_f32(float *x, const float *e_theta, const float *noise, long long n, float s1, float s2, float s3,
+                                   float s4, float sigma, int last, void *stream)
+{
+    LDM_REQUIRE(x && e_theta && n > 0, "ldm_ddim_update_f32: null pointer / empty");
+    LDM_REQUIRE(noise || sigma == 0.f, "ldm_ddim_update_f32: sigma != 0 needs noise");
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, e_theta, noise, n, s1, s2, s3, s4, sigma, last);
+    LDM_CHECK_LAUNCH("ldm_ddim_update_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_qsample_f32(const float *x, const float *e, const float *sa, const float *sb, float *out, int B, long long per_sample, void *stream)
+{
+    LDM_REQUIRE(x && e && sa && sb && out && B > 0 && per_sample > 0, "ldm_qsample_f32: bad arguments");
+    const long long n = (long long)B * per_sample;
+    hipLaunchKernelGGL(qsample_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, e, sa, sb, out, n, per_sample);
+    LDM_CHECK_LAUNCH("ldm_qsample_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_rgb_head_f32(const float *x, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(x && w && bias && out, "ldm_rgb_head_f32: null pointer");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "ldm_rgb_head_f32: bad shape");
+    LDM_REQUIRE(!prev || (H % 2 == 0 && W % 2 == 0), "ldm_rgb_head_f32: prev needs even H, W");
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(w), "ldm_rgb_head_f32: unaligned pointer");
+    const int lpr = pow2_lanes(C / 4) > 16 ? 16 : pow2_lanes(C / 4);
+    const long long rows = (long long)B * H * W;
+    const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL(rgb_head_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, prev, out, B, H, W, C, lpr);
+    LDM_CHECK_LAUNCH("ldm_rgb_head_f32");
+    return LDM_OK;
+}
+
+static int transpose_launch(const float *x, float *out, int B, int R, int Cc, void *stream, const char *who)
+{
+    LDM_REQUIRE(x && out && B > 0 && R > 0 && Cc > 0, "%s: bad arguments", who);
+    LDM_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.z", who, B);
+    dim3 grid((Cc + 31) / 32, (R + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, R, Cc);
+    LDM_CHECK_LAUNCH(who);
+    return LDM_OK;
+}
+
+extern "C" int ldm_nchw_to_nhwc_f32(const float *x, float *out, int B, int C, int HW, void *stream)
+{
+    return transpose_launch(x, out, B, C, HW, stream, "ldm_nchw_to_nhwc_f32");
+}
+
+extern "C" int ldm_nhwc_to_nchw_f32(const float *x, float *out, int B, int C, int HW, void *stream)
+{
+    return transpose_launch(x, out, B, HW, C, stream, "ldm_nhwc_to_nchw_f32");
+}
+
+extern "C" int ldm_to_uint8_hwc(const float *img, unsigned char *out, int B, int C, int HW, void *stream)
+{
+    LDM_REQUIRE(img && out && B > 0 && C > 0 && HW > 0, "ldm_to_uint8_hwc: bad arguments");
+    const long long total = (long long)B * C * HW;
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, B, C, HW);
+    LDM_CHECK_LAUNCH("ldm_to_uint8_hwc");
+    return LDM_OK;
+}

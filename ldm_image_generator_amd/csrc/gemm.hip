@@ -1,0 +1,403 @@
+// fp32 GEMM family on the exact-fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD, bit-for-bit an fmaf chain).
+//
+//     out = act(A . W^T + bias) (+ addend)
+//
+// One 256-thread workgroup (4 waves) owns a BM x BN output tile; each wave owns
+// TM x TN accumulator tiles of 32x32.  K is walked in steps of 32 floats: both
+// operands are K-contiguous ("NT"), so a tile row is one full 128-B line.
+// Global -> registers -> LDS staging, two LDS stages, one barrier per K-step
+// (loads for step k+1 are issued before the MFMAs of step k and written to LDS
+// after them).  LDS rows are 128 B with a 16-B-chunk XOR swizzle
+// (chunk ^= (row>>1)&7) that makes both the ds_write_b128 staging stores and the
+// ds_read_b128 fragment reads bank-conflict free.  A fragment read hands each lane
+// four consecutive k of its row; they feed four MFMA k-steps (the k order inside
+// a 32-float step is a fixed permutation, identical for A and W).
+//
+// Variants (template): tile shape, GATE (two weight matrices per tile, epilogue
+// a*relu(b): the ReGLU of modules.py:15), A addressing (rows | implicit 3x3
+// im2col).  Runtime: weight segments selected by pointer (RandomMoE experts are
+// never copied), bias/activation/addend, output scatter (rows | ConvTranspose
+// 2x2 | nearest-x2 replicate), groups on grid.y.
+#include "common.h"
+#include <vector>
+#include <mutex>
+
+namespace {
+
+struct GemmP {
+    const float *a;
+    long long lda;
+    int M, N, K;
+    int H, W, Cin, cpt;          // conv: chunks (of 32 channels) per tap
+    int nseg, seg_mode, seg_len;
+    const float *w[LDM_MAX_SEG];
+    const float *w2[LDM_MAX_SEG];
+    const float *bias[LDM_MAX_SEG];
+    const float *bias2[LDM_MAX_SEG];
+    long long ldw;
+    int act;
+    float slope;
+    const float *addend;
+    long long ldadd;
+    float *out;
+    long long ldo;
+    int o_mode, OH, OW, Cout;
+    long long a_gstride, w_gstride, o_gstride;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NB = GATE ? 2 * BN : BN;
+    constexpr int A_F4 = BM / 32, B_F4 = NB / 32;
+    constexpr int STAGE = (BM + NB) * 32;
+    constexpr int NACC = GATE ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    const int ntn = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
+    const int chunk = t & 7, lrow = t >> 3;
+    const int nk = p.K >> 5;
+
+    // ---- per-thread A rows -------------------------------------------------
+    const float *a_base = p.a + g * p.a_gstride + chunk * 4;
+    long long a_off[A_F4];
+    bool a_ok[A_F4];
+    int a_y[A_F4], a_x[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        a_ok[i] = m < p.M;
+        a_off[i] = (long long)m * p.lda;
+        if (AMODE == LDM_A_CONV3X3) {
+            a_x[i] = m % p.W;
+            a_y[i] = (m / p.W) % p.H;
+        }
+    }
+    // ---- per-thread W rows -------------------------------------------------
+    // rows [0,BN) come from w, rows [BN,2BN) (GATE) from w2
+    const int seg_n = (p.seg_mode == LDM_SEG_N) ? n0 / p.seg_len : 0;
+    const int nloc0 = (p.seg_mode == LDM_SEG_N) ? n0 - seg_n * p.seg_len : n0;
+
+    f32x4 areg[A_F4], breg[B_F4];
+
+    auto load_tiles = [&](int kt) {
+        if (AMODE == LDM_A_CONV3X3) {
+            const int tap = kt / p.cpt;
+            const int c0 = (kt - tap * p.cpt) << 5;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long long shift = (long long)(dy * p.W + dx) * p.lda + c0;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const bool ok = a_ok[i] && (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
+                areg[i] = ok ? *(const f32x4 *)(a_base + a_off[i] + shift) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i)
+                areg[i] = a_ok[i] ? *(const f32x4 *)(a_base + a_off[i] + ((long long)kt << 5)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        int seg = seg_n;
+        long long kcol = (long long)kt << 5;
+        if (p.seg_mode == LDM_SEG_K) {
+            seg = (kt << 5) / p.seg_len;
+            kcol -= (long long)seg * p.seg_len;
+        }
+        const float *wa = p.w[seg] + g * p.w_gstride + kcol + chunk * 4;
+        const float *wb = GATE ? p.w2[seg] + g * p.w_gstride + kcol + chunk * 4 : nullptr;
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int row = lrow + 32 * i;
+            if (GATE && row >= BN)
+                breg[i] = *(const f32x4 *)(wb + (long long)(nloc0 + row - BN) * p.ldw);
+            else
+                breg[i] = *(const f32x4 *)(wa + (long long)(nloc0 + row) * p.ldw);
+        }
+    };
+    auto store_tiles = [&](int stage) {
+        float *As = lds + stage * STAGE, *Bs = As + BM * 32;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) *(f32x4 *)(As + swz(lrow + 32 * i, chunk)) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) *(f32x4 *)(Bs + swz(lrow + 32 * i, chunk)) = breg[i];
+    };
+
+    f32x16 acc[NACC][TM][TN];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float *As = lds + cur * STAGE, *Bs = As + BM * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 2 * j + h;
+            f32x4 af[TM], bf[NACC][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4 *)(As + swz((wm * TM + i) * 32 + r, c));
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) bf[q][i] = *(const f32x4 *)(Bs + swz(q * BN + (wn * TN + i) * 32 + r, c));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            acc[q][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[q][jj][e], acc[q][i][jj], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------
+    const long long gcol = g * p.o_gstride;
+    float b1[TN], b2[TN];
+    int q4[TN];
+    long long ocol[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int nloc = n0 + (wn * TN + jn) * 32 + r;      // column inside this group's N
+        int bidx = (p.seg_mode == LDM_SEG_N) ? nloc - seg_n * p.seg_len : nloc;
+        int co = nloc;
+        q4[jn] = 0;
+        if (p.o_mode == LDM_O_CONVT2X2) {
+            q4[jn] = nloc / p.Cout;
+            co = nloc - q4[jn] * p.Cout;
+            bidx = co;
+        }
+        ocol[jn] = gcol + co;
+        b1[jn] = 0.f;
+        b2[jn] = 0.f;
+        if (p.seg_mode == LDM_SEG_K) {
+            if (p.bias[0]) b1[jn] += p.bias[0][gcol + bidx];
+            if (p.nseg > 1 && p.bias[1]) b1[jn] += p.bias[1][gcol + bidx];
+            if (p.nseg > 2 && p.bias[2]) b1[jn] += p.bias[2][gcol + bidx];
+            if (p.nseg > 3 && p.bias[3]) b1[jn] += p.bias[3][gcol + bidx];
+        } else {
+            if (p.bias[seg_n]) b1[jn] = p.bias[seg_n][gcol + bidx];
+            if (GATE && p.bias2[seg_n]) b2[jn] = p.bias2[seg_n][gcol + bidx];
+        }
+    }
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const bool live = m < p.M;
+            long long orow0 = m;
+            int ox2 = 0;
+            if (p.o_mode != LDM_O_ROWS) {
+                const int xx = m % p.OW;
+                const int yy = (m / p.OW) % p.OH;
+                const long long bb = m / (p.OW * p.OH);
+                ox2 = 2 * p.OW;
+                orow0 = (bb * 2 * p.OH + 2 * yy) * ox2 + 2 * xx;        // top-left fine pixel
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                float v = acc[0][im][jn][e] + b1[jn];
+                if (GATE) {
+                    const float gt = acc[NACC - 1][im][jn][e] + b2[jn];
+                    v = v * fmaxf(gt, 0.f);
+                } else if (p.act == LDM_ACT_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (p.act == LDM_ACT_LRELU) {
+                    v = v > 0.f ? v : v * p.slope;
+                }
+                if (live) {
+                    if (p.o_mode == LDM_O_UP2) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const long long orow = orow0 + (d >> 1) * ox2 + (d & 1);
+                            float o = v;
+                            if (p.addend) o += p.addend[orow * p.ldadd + ocol[jn]];
+                            p.out[orow * p.ldo + ocol[jn]] = o;
+                        }
+                    } else {
+                        const long long orow = orow0 + (q4[jn] >> 1) * ox2 + (q4[jn] & 1);
+                        if (p.addend) v += p.addend[orow * p.ldadd + ocol[jn]];
+                        p.out[orow * p.ldo + ocol[jn]] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t start, stop;
+    double flops;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_pool;
+size_t g_prof_used = 0;
+
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
+int launch(const GemmP &p, int groups, hipStream_t st)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NB = GATE ? 2 * BN : BN;
+    constexpr size_t smem = 2ull * (BM + NB) * 32 * sizeof(float);
+    static bool attr_done = false;
+    auto kern = gemm_f32_kernel<WM, WN, TM, TN, GATE, AMODE>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    dim3 grid(ntm * ntn, groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    return 0;
+}
+
+template <bool GATE, int AMODE>
+int dispatch(const GemmP &p, int groups, hipStream_t st)
+{
+    const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;     // BN must divide this
+    if (GATE) {
+        if (unit % 64 == 0) return launch<2, 2, 2, 1, GATE, AMODE>(p, groups, st);
+        return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);
+    }
+    if (p.M <= 32 && unit % 128 == 0) return launch<1, 4, 1, 1, GATE, AMODE>(p, groups, st);
+    if (unit % 128 == 0) return launch<2, 2, 2, 2, GATE, AMODE>(p, groups, st);
+    if (unit % 64 == 0) return launch<2, 2, 2, 1, GATE, AMODE>(p, groups, st);
+    return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);
+}
+
+}  // namespace
+
+extern "C" int ldm_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return LDM_OK;
+}
+
+extern "C" int ldm_prof_read(long long *launches, double *ms, double *flops)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tms = 0.0, tf = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float e = 0.f;
+        if (hipEventSynchronize(g_prof_pool[i].stop) != hipSuccess || hipEventElapsedTime(&e, g_prof_pool[i].start, g_prof_pool[i].stop) != hipSuccess) {
+            ldm_set_error("ldm_prof_read: event %zu not readable", i);
+            return LDM_ELAUNCH;
+        }
+        tms += e;
+        tf += g_prof_pool[i].flops;
+    }
+    if (launches) *launches = (long long)g_prof_used;
+    if (ms) *ms = tms;
+    if (flops) *flops = tf;
+    g_prof_used = 0;
+    return LDM_OK;
+}
+
+extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
+{
+    LDM_REQUIRE(d != nullptr, "ldm_gemm_f32: null descriptor");
+    LDM_REQUIRE(d->a && d->out, "ldm_gemm_f32: null operand");
+    LDM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "ldm_gemm_f32: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    LDM_REQUIRE(d->N % 32 == 0 && d->K % 32 == 0, "ldm_gemm_f32: N=%d and K=%d must be multiples of 32", d->N, d->K);
+    LDM_REQUIRE(d->nseg >= 1 && d->nseg <= LDM_MAX_SEG, "ldm_gemm_f32: nseg=%d", d->nseg);
+    LDM_REQUIRE(d->lda % 4 == 0 && d->ldw % 4 == 0, "ldm_gemm_f32: lda/ldw must be multiples of 4 floats");
+    LDM_REQUIRE(ldm_aligned16(d->a), "ldm_gemm_f32: A not 16-byte aligned");
+    const bool gate = d->act == LDM_ACT_GATE;
+    const int groups = d->groups > 0 ? d->groups : 1;
+    LDM_REQUIRE(d->a_gstride % 4 == 0 && d->w_gstride % 4 == 0, "ldm_gemm_f32: group strides must be multiples of 4 floats");
+    LDM_REQUIRE(d->seg_mode == LDM_SEG_N || d->seg_mode == LDM_SEG_K, "ldm_gemm_f32: seg_mode=%d", d->seg_mode);
+    const int seg_total = d->seg_mode == LDM_SEG_N ? d->N : d->K;
+    const int seg_len = d->nseg == 1 ? seg_total : d->seg_len;
+    LDM_REQUIRE(seg_len > 0 && seg_len % 32 == 0 && (long long)seg_len * d->nseg == seg_total,
+                "ldm_gemm_f32: segments (%d x %d) do not cover %d", d->nseg, seg_len, seg_total);
+    LDM_REQUIRE(!(gate && d->seg_mode == LDM_SEG_K && d->nseg > 1), "ldm_gemm_f32: GATE with K-segments is not supported");
+    for (int s = 0; s < d->nseg; ++s) {
+        LDM_REQUIRE(d->w[s] && ldm_aligned16(d->w[s]), "ldm_gemm_f32: weight segment %d null/unaligned", s);
+        if (gate) LDM_REQUIRE(d->w2[s] && ldm_aligned16(d->w2[s]), "ldm_gemm_f32: gate weight segment %d null/unaligned", s);
+    }
+    GemmP p{};
+    p.a = d->a; p.lda = d->lda; p.M = d->M; p.N = d->N; p.K = d->K;
+    p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.cpt = 1;
+    if (d->a_mode == LDM_A_CONV3X3) {
+        LDM_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin, "ldm_gemm_f32: conv3x3 needs K == 9*Cin, Cin %% 32 == 0");
+        LDM_REQUIRE(d->M % (d->H * d->W) == 0, "ldm_gemm_f32: conv3x3 M=%d is not a multiple of H*W", d->M);
+        p.cpt = d->Cin / 32;
+    } else {
+        LDM_REQUIRE(d->a_mode == LDM_A_ROWS, "ldm_gemm_f32: a_mode=%d", d->a_mode);
+    }
+    p.nseg = d->nseg; p.seg_mode = d->seg_mode;
+    p.seg_len = seg_len;
+    for (int s = 0; s < LDM_MAX_SEG; ++s) {
+        p.w[s] = s < d->nseg ? d->w[s] : nullptr;
+        p.w2[s] = s < d->nseg ? d->w2[s] : nullptr;
+        p.bias[s] = s < d->nseg ? d->bias[s] : nullptr;
+        p.bias2[s] = s < d->nseg ? d->bias2[s] : nullptr;
+    }
+    p.ldw = d->ldw; p.act = d->act; p.slope = d->slope;
+    p.addend = d->addend; p.ldadd = d->ldadd; p.out = d->out; p.ldo = d->ldo;
+    p.o_mode = d->o_mode; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
+    if (d->o_mode != LDM_O_ROWS) {
+        LDM_REQUIRE(d->OH > 0 && d->OW > 0 && d->M % (d->OH * d->OW) == 0, "ldm_gemm_f32: scatter output needs M %% (OH*OW) == 0");
+        if (d->o_mode == LDM_O_CONVT2X2) LDM_REQUIRE(d->Cout > 0 && d->N == 4 * d->Cout, "ldm_gemm_f32: convT2x2 needs N == 4*Cout");
+    }
+    p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.o_gstride = d->o_gstride;
+
+    hipStream_t st = (hipStream_t)stream;
+    ProfRec *rec = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_on) {
+            if (g_prof_used == g_prof_pool.size()) {
+                ProfRec r{};
+                if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+                    ldm_set_error("ldm_gemm_f32: hipEventCreate failed");
+                    return LDM_ELAUNCH;
+                }
+                g_prof_pool.push_back(r);
+            }
+            rec = &g_prof_pool[g_prof_used++];
+            rec->flops = 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0);
+            (void)hipEventRecord(rec->start, st);
+        }
+    }
+    if (gate) {
+        if (d->a_mode == LDM_A_CONV3X3) { ldm_set_error("ldm_gemm_f32: GATE with conv3x3 unsupported"); return LDM_EINVAL; }
+        dispatch<true, LDM_A_ROWS>(p, groups, st);
+    } else if (d->a_mode == LDM_A_CONV3X3) {
+        dispatch<false, LDM_A_CONV3X3>(p, groups, st);
+    } else {
+        dispatch<false, LDM_A_ROWS>(p, groups, st);
+    }
+    if (rec) (void)hipEventRecord(rec->stop, st);
+    LDM_CHECK_LAUNCH("ldm_gemm_f32");
+    return LDM_OK;
+}

@@ -1,0 +1,98 @@
+"""DDPM training loss / DDIM sampler (reference: ddpm.py:11-93), MI355X-native host side.
+
+Same constructor and method signatures as the reference.  Schedule tables stay
+plain CPU tensors (not buffers -- ``state_dict`` is ``model.*`` only, like the
+reference).  Per step the host computes the four DDIM scalars with the
+reference's own fp32 expressions and the update runs as one fused elementwise
+kernel that rounds exactly like the reference's separate torch ops.
+
+Differences, all deliberate and documented in DESIGN.md:
+  * ``model=None`` builds a fresh ``UNet()`` per instance (the reference evaluates
+    ``UNet()`` once at import and shares it between instances, ddpm.py:16);
+  * ``use_autocast`` is accepted and ignored: the HIP path always computes in
+    fp32, which is what the reference's CPU path does (ddpm.py:75 is a no-op there);
+  * ``sample(..., x_init=)`` optionally injects x_T (parity tests need a
+    CPU-generated start; the reference draws it on the model's device).
+"""
+import random
+
+import torch
+import torch.nn as nn
+from tqdm import tqdm
+
+from . import ops
+from .unet import UNet
+
+
+class DDPM(nn.Module):
+    def __init__(self, model=None, beta_min=1e-4, beta_max=0.02, num_timesteps=1000, loss_function=nn.L1Loss(),
+                 lambda_max=20, lambda_min=-20):
+        super().__init__()
+        self.model = UNet() if model is None else model
+        self.beta = torch.linspace(beta_min, beta_max, num_timesteps)
+        self.alpha = 1 - self.beta
+        self.num_timesteps = num_timesteps
+        self.loss_function = loss_function
+        self.lambda_max = lambda_max
+        self.lambda_min = lambda_min
+        # ddpm.py:28-37, same expressions (prefix products, then beta_tilde)
+        self.alpha_bar = torch.Tensor([torch.prod(self.alpha[:t]) for t in range(1, num_timesteps + 1)])
+        bt = [1]
+        for t in range(1, num_timesteps):
+            bt.append((1 - self.alpha_bar[t - 1]) / (1 - self.alpha_bar[t]) * self.beta[t])
+        self.beta_tilde = torch.Tensor(bt)
+
+    def calculate_loss(self, x, condition=None):
+        """ddpm.py:39-48.  The UNet forward runs on the HIP path; see train.py for the backward."""
+        t = torch.randint(low=1, high=self.num_timesteps, size=(x.shape[0],))
+        alpha_bar_t = torch.index_select(self.alpha_bar, 0, t)
+        e = torch.randn(*x.shape, device=x.device)
+        sa = torch.sqrt(alpha_bar_t).to(x.device)
+        sb = torch.sqrt(1 - alpha_bar_t).to(x.device)
+        xt = torch.empty_like(x, dtype=torch.float32)
+        ops.qsample(x.contiguous().float(), e, sa, sb, xt)
+        t = t.to(x.device)
+        e_theta = self.model(x=xt, time=t, condition=condition)
+        return self.loss_function(e_theta, e)
+
+    @torch.no_grad()
+    def sample(self, x_shape=(1, 3, 64, 64), condition=None, seed=None, num_steps=20, use_autocast=True, schedule='linear',
+               eta=0, x_init=None, progress=True):
+        device = next(self.model.parameters()).device
+        if seed is not None:
+            random.seed(seed)
+            torch.manual_seed(seed)
+            torch.cuda.manual_seed(seed)
+        x = torch.randn(*x_shape, device=device)                 # drawn even when x_init is given (RNG parity)
+        if x_init is not None:
+            x = x_init.to(device=device, dtype=torch.float32).clone()
+        if schedule == 'linear':
+            steps = [int(s) for s in torch.linspace(0, self.num_timesteps - 1, num_steps).int()]
+        elif type(schedule) == list:
+            steps = schedule
+        else:
+            raise TypeError(f"schedule \"{schedule}\" is not implemented.")   # the reference raises a str -> TypeError
+        steps_next = [0] + steps[:-1]
+        alpha = torch.cumprod((1 - self.beta), dim=0)
+        bar = tqdm(total=len(steps), disable=not progress)
+        hint_ok = hasattr(self.model, "_uniform_time")
+        try:
+            for t, t_next in zip(reversed(steps), reversed(steps_next)):
+                t_tensor = torch.full((x_shape[0],), t, device=device)
+                if hint_ok:
+                    self.model._uniform_time = t                 # every sample shares t: FiLM computed once
+                e_theta = self.model(x=x, time=t_tensor, condition=None)
+                e = torch.randn(*x_shape, device=device)
+                sigma = eta * torch.sqrt((1 - alpha[t_next]) / (1 - alpha[t])) * torch.sqrt(1 - alpha[t] / alpha[t_next])
+                s1 = torch.sqrt(1 - alpha[t])
+                s2 = torch.sqrt(alpha[t])
+                s3 = torch.sqrt(alpha[t_next])
+                s4 = torch.sqrt(1 - alpha[t_next] - sigma ** 2)
+                bar.set_description(f"t: {t}, sigma: {sigma}")
+                ops.ddim_update(x, e_theta, e, float(s1), float(s2), float(s3), float(s4), float(sigma), t == 0)
+                bar.update(1)
+        finally:
+            if hint_ok:
+                self.model._uniform_time = None
+            bar.close()
+        return x

@@ -1,0 +1,76 @@
+"""Data-parallel sampling: shard the sample batch, one all-gather at the end.
+
+Samples never interact anywhere on the path (per-pixel norm, per-window attention,
+no batch statistics -- SURVEY.md 8e), so rank r simply owns the contiguous slice
+[r*B/N, (r+1)*B/N) of the global batch; weights are replicated; every rank seeds
+Python's ``random`` identically so expert/skip decisions equal the unsharded run.
+There is NO collective inside the 50-step loop or the decode; the only exchange is
+one all-gather of the finished images (RCCL over xGMI when the backend is "nccl").
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(global_batch, rank, world):
+    """Contiguous, balanced slices (the first ``global_batch % world`` ranks get one extra)."""
+    base, extra = divmod(global_batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def global_noise(global_batch, latent_shape, seed):
+    """x_T for the WHOLE job from one CPU generator, so sharded == unsharded sample-for-sample."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(global_batch, *latent_shape, generator=g)
+
+
+def gather_images(local_images, global_batch, rank, world):
+    """One all-gather of the per-rank results into [global_batch, ...] on every rank."""
+    if world == 1:
+        return local_images
+    base, extra = divmod(global_batch, world)
+    if extra == 0:
+        out = torch.empty((global_batch,) + tuple(local_images.shape[1:]), dtype=local_images.dtype, device=local_images.device)
+        dist.all_gather_into_tensor(out, local_images.contiguous())
+        return out
+    # ragged: pad every shard to the largest, gather, then drop the padding
+    big = base + 1
+    pad = torch.zeros((big,) + tuple(local_images.shape[1:]), dtype=local_images.dtype, device=local_images.device)
+    pad[: local_images.shape[0]] = local_images
+    out = torch.empty((world * big,) + tuple(local_images.shape[1:]), dtype=local_images.dtype, device=local_images.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(global_batch, r, world)
+        parts.append(out[r * big: r * big + (hi - lo)])
+    return torch.cat(parts, dim=0)
+
+
+def sample_images_sharded(sample_fn, decode_fn, global_batch, latent_shape, seed, rank, world, device, gather=True):
+    """Run ``decode_fn(sample_fn(x_T_slice))`` on this rank's slice and all-gather the images.
+
+    sample_fn(x_T [b, ...] on device) -> latents; decode_fn(latents) -> images.  Every
+    rank must call with the same (global_batch, latent_shape, seed).
+    """
+    lo, hi = shard_bounds(global_batch, rank, world)
+    x_t = global_noise(global_batch, latent_shape, seed)[lo:hi].to(device)
+    images = decode_fn(sample_fn(x_t))
+    return gather_images(images, global_batch, rank, world) if gather else images

@@ -1,0 +1,180 @@
+"""Thin tensor-level wrappers over the C ABI (include/ldm_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every function
+hands raw ``data_ptr()`` addresses and the current HIP stream to the library and
+returns immediately (kernels are only enqueued).  Nothing in this file computes
+on the CPU and nothing falls back to ATen ops.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O_CONVT2X2, O_ROWS, O_UP2, SEG_K, SEG_N,
+                   GemmDesc)
+
+__all__ = ["gemm", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
+           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read",
+           "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
+           "SEG_N", "SEG_K"]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.LdmHipUnavailable(
+            "%s must be a GPU tensor: the HIP path is the only implementation (no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _opt(t, name, dtype=torch.float32):
+    return None if t is None else _dev(t, name, dtype)
+
+
+def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=None, biases2=None, ldw=None,
+         seg_mode=SEG_N, act=ACT_NONE, slope=0.0, addend=None, ldadd=None, a_mode=A_ROWS, conv_hw=None, cin=0,
+         o_mode=O_ROWS, out_hw=None, cout=0, groups=1, a_gstride=0, w_gstride=0, o_gstride=0):
+    """out = act(A . W^T + bias) (+ addend); see struct ldm_gemm_desc."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.a = _dev(a, "a")
+    d.lda = K if lda is None else lda
+    d.M, d.N, d.K = M, N, K
+    d.a_mode = a_mode
+    if conv_hw is not None:
+        d.H, d.W = conv_hw
+    d.Cin = cin
+    nseg = len(weights)
+    d.nseg = nseg
+    d.seg_mode = seg_mode
+    d.seg_len = (N if seg_mode == SEG_N else K) // nseg
+    for s in range(nseg):
+        d.w[s] = _dev(weights[s], "weight")
+        if weights2 is not None:
+            d.w2[s] = _dev(weights2[s], "weight2")
+        if biases is not None and biases[s] is not None:
+            d.bias[s] = _dev(biases[s], "bias")
+        if biases2 is not None and biases2[s] is not None:
+            d.bias2[s] = _dev(biases2[s], "bias2")
+    if ldw is None:
+        ldw = K if seg_mode == SEG_N else K // nseg
+    d.ldw = ldw
+    d.act = act
+    d.slope = slope
+    d.addend = _opt(addend, "addend")
+    d.ldadd = (N if ldadd is None else ldadd)
+    d.out = _dev(out, "out")
+    d.ldo = N if ldo is None else ldo
+    d.o_mode = o_mode
+    if out_hw is not None:
+        d.OH, d.OW = out_hw
+    d.Cout = cout
+    d.groups = groups
+    d.a_gstride, d.w_gstride, d.o_gstride = a_gstride, w_gstride, o_gstride
+    _lib.check(lib.ldm_gemm_f32(ctypes.byref(d), _stream()), "ldm_gemm_f32")
+    return out
+
+
+def channelnorm_film(x, film, slot, out, B, HW, C, eps=1e-4):
+    lib = _lib.load()
+    _lib.check(lib.ldm_channelnorm_film_f32(_dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32),
+                                            _dev(out, "out"), B, HW, C, eps, _stream()), "ldm_channelnorm_film_f32")
+    return out
+
+
+def film(x, film_rows, slot, out, B, HW, C):
+    lib = _lib.load()
+    _lib.check(lib.ldm_film_f32(_dev(x, "x"), _dev(film_rows, "film"), _opt(slot, "slot", torch.int32), _dev(out, "out"),
+                                B, HW, C, _stream()), "ldm_film_f32")
+    return out
+
+
+def sincos_embed(t, H, W, C, pos_freq, time_freq, out):
+    lib = _lib.load()
+    _lib.check(lib.ldm_sincos_embed_f32(_dev(t, "t", torch.int64), t.numel(), H, W, C, _dev(pos_freq, "pos_freq"),
+                                        _dev(time_freq, "time_freq"), _dev(out, "emb"), _stream()), "ldm_sincos_embed_f32")
+    return out
+
+
+def window_attention(qkv, in_proj_bias, xf, out, B, H, W, C, ws, shift):
+    lib = _lib.load()
+    _lib.check(lib.ldm_window_attention_f32(_dev(qkv, "qkv"), _dev(in_proj_bias, "in_proj_bias"), _opt(xf, "xf"),
+                                            _dev(out, "out"), B, H, W, C, ws, shift, _stream()), "ldm_window_attention_f32")
+    return out
+
+
+def avgpool2(x, out, B, H, W, C):
+    lib = _lib.load()
+    _lib.check(lib.ldm_avgpool2_f32(_dev(x, "x"), _dev(out, "out"), B, H, W, C, _stream()), "ldm_avgpool2_f32")
+    return out
+
+
+def stem_nchw(x, w, bias, out, B, Cin, HW, C0):
+    lib = _lib.load()
+    _lib.check(lib.ldm_stem_nchw_f32(_dev(x, "x"), _dev(w, "w"), _opt(bias, "bias"), _dev(out, "out"), B, Cin, HW, C0,
+                                     _stream()), "ldm_stem_nchw_f32")
+    return out
+
+
+def head_nchw(x, w, bias, out, B, C0, HW, Cin):
+    lib = _lib.load()
+    _lib.check(lib.ldm_head_nchw_f32(_dev(x, "x"), _dev(w, "w"), _opt(bias, "bias"), _dev(out, "out"), B, C0, HW, Cin,
+                                     _stream()), "ldm_head_nchw_f32")
+    return out
+
+
+def ddim_update(x, e_theta, noise, s1, s2, s3, s4, sigma, last):
+    lib = _lib.load()
+    _lib.check(lib.ldm_ddim_update_f32(_dev(x, "x"), _dev(e_theta, "e_theta"), _opt(noise, "noise"), x.numel(),
+                                       s1, s2, s3, s4, sigma, int(last), _stream()), "ldm_ddim_update_f32")
+    return x
+
+
+def qsample(x, e, sa, sb, out):
+    lib = _lib.load()
+    B = x.shape[0]
+    _lib.check(lib.ldm_qsample_f32(_dev(x, "x"), _dev(e, "e"), _dev(sa, "sa"), _dev(sb, "sb"), _dev(out, "out"), B,
+                                   x.numel() // B, _stream()), "ldm_qsample_f32")
+    return out
+
+
+def rgb_head(x, w, bias, prev, out, B, H, W, C):
+    lib = _lib.load()
+    _lib.check(lib.ldm_rgb_head_f32(_dev(x, "x"), _dev(w, "w"), _dev(bias, "bias"), _opt(prev, "prev"), _dev(out, "out"),
+                                    B, H, W, C, _stream()), "ldm_rgb_head_f32")
+    return out
+
+
+def nchw_to_nhwc(x, out, B, C, HW):
+    lib = _lib.load()
+    _lib.check(lib.ldm_nchw_to_nhwc_f32(_dev(x, "x"), _dev(out, "out"), B, C, HW, _stream()), "ldm_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x, out, B, C, HW):
+    lib = _lib.load()
+    _lib.check(lib.ldm_nhwc_to_nchw_f32(_dev(x, "x"), _dev(out, "out"), B, C, HW, _stream()), "ldm_nhwc_to_nchw_f32")
+    return out
+
+
+def to_uint8_hwc(img, out, B, C, HW):
+    lib = _lib.load()
+    _lib.check(lib.ldm_to_uint8_hwc(_dev(img, "img"), _dev(out, "out", torch.uint8), B, C, HW, _stream()), "ldm_to_uint8_hwc")
+    return out
+
+
+def prof_enable(on):
+    _lib.check(_lib.load().ldm_prof_enable(1 if on else 0), "ldm_prof_enable")
+
+
+def prof_read():
+    n, ms, fl = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
+    _lib.check(_lib.load().ldm_prof_read(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "ldm_prof_read")
+    return n.value, ms.value, fl.value

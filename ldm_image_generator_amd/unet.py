@@ -1,0 +1,224 @@
+"""Swin-style UNet (reference: unet.py:9-103), MI355X-native host side.
+
+Drop-in surface: ``UNet(input_channels=8, stages=[3,3,9,3], channels=[128,256,512,1024],
+stem_size=1).forward(x, time, condition=None)`` with NCHW tensors, the reference's
+``state_dict`` keys (1376 tensors at the default size), the reference's default
+initialisation (same module construction order, so the same ``torch.manual_seed``
+gives the same weights) and the reference's consumption of Python's global
+``random`` (stochastic depth + expert choice, in block order).
+
+Inside, activations are channels-last rows [M = B*H*W, C]; per SwinBlock the
+launches are
+    channelnorm_film -> grouped-3x3 GEMM (+bias +residual)
+                     -> [in-proj GEMM -> window attention -> out-proj GEMM (+=)]
+                     -> gated GEMM (a*relu(b), 3 experts by pointer) -> GEMM over stacked K (+=)
+and the FiLM (mul | bias) of each block is produced once per distinct timestep
+by two GEMMs over the sin/cos code table (batch-independent).
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from . import ops, sinusoidal
+from .attention import CrossAttention, WindowAttention
+from .modules import ChannelNorm, RandomMoE, from_rows, to_rows, w2d
+from .sinusoidal import PositionalEncoding2d, TimeEncoding2d
+
+
+class TimeContext:
+    """Per-forward bookkeeping: distinct timesteps, sample->slot map, and the
+    sin/cos code table of every (C, H, W) seen so far (shared by all blocks of a level)."""
+
+    def __init__(self, time, batch, device, uniform=None):
+        if uniform is not None:
+            self.t_unique = torch.tensor([int(uniform)], dtype=torch.int64, device=device)
+            self.slot = None
+        else:
+            tc = time.detach().to("cpu", torch.int64)             # one host sync per forward
+            uniq, inv = torch.unique(tc, return_inverse=True)
+            self.t_unique = uniq.to(device)
+            self.slot = None if uniq.numel() == 1 else inv.to(device=device, dtype=torch.int32)
+        self.batch = batch
+        self._codes = {}
+
+    def codes(self, channels, height, width):
+        key = (channels, height, width)
+        if key not in self._codes:
+            self._codes[key] = sinusoidal.embed(self.t_unique, height, width, channels)
+        return self._codes[key]
+
+
+class Encodings(nn.Module):
+    """FiLM from position + time codes (unet.py:9-23)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.proj1 = nn.Conv2d(channels * 2, channels * 4, 1, 1, 0)
+        self.act = nn.ReLU()
+        self.proj2 = nn.Conv2d(channels * 4, channels * 2, 1, 1, 0)
+        self.pe = PositionalEncoding2d(channels, return_encoding_only=True)
+        self.te = TimeEncoding2d(channels, return_encoding_only=True)
+        self.channels = channels
+
+    def film_rows(self, codes):
+        """codes [nT*HW, 2C] -> (mul | bias) rows [nT*HW, 2C]  (unet.py:20)."""
+        m = codes.shape[0]
+        c = self.channels
+        hid = torch.empty(m, 4 * c, device=codes.device, dtype=torch.float32)
+        ops.gemm(codes, m, 4 * c, 2 * c, [w2d(self.proj1)], hid, biases=[self.proj1.bias.detach()], act=ops.ACT_RELU)
+        film = torch.empty(m, 2 * c, device=codes.device, dtype=torch.float32)
+        ops.gemm(hid, m, 2 * c, 4 * c, [w2d(self.proj2)], film, biases=[self.proj2.bias.detach()])
+        return film
+
+    def forward(self, x, t):
+        rows, (b, h, w) = to_rows(x)
+        ctx = TimeContext(t, b, x.device)
+        film = self.film_rows(ctx.codes(self.channels, h, w))
+        out = torch.empty_like(rows)
+        ops.film(rows, film, ctx.slot, out, b, h * w, self.channels)
+        return from_rows(out, (b, h, w))
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, channels, head_dim=32, window_size=6, shift=0, attention=True, stochastic_depth=0.25):
+        super().__init__()
+        if head_dim != 32:
+            raise NotImplementedError("HIP kernels are specialised for head_dim == 32 (the reference's only value)")
+        self.norm = ChannelNorm(channels)
+        self.ffn = RandomMoE(channels)
+        self.conv = nn.Conv2d(channels, channels, 3, 1, 1, groups=channels // head_dim)
+        self.stochastic_depth = stochastic_depth
+        self.attention_flag = attention
+        if attention:
+            self.self_attention = WindowAttention(channels, n_heads=channels // head_dim, window_size=window_size, shift=shift)
+            self.cross_attention = CrossAttention(channels, n_heads=channels // head_dim)
+        self.encodings = Encodings(channels)
+        self.channels = channels
+        self._packed = None
+
+    def _conv_weight(self):
+        """[C, 32, 3, 3] -> [C][tap][32] (K contiguous for the implicit-GEMM), cached per weight version."""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version)
+        if self._packed is None or self._packed[0] != key:
+            c = w.shape[0]
+            self._packed = (key, w.detach().permute(0, 2, 3, 1).reshape(c, 9 * w.shape[1]).contiguous())
+        return self._packed[1]
+
+    def forward_rows(self, rows, shape, ctx):
+        """unet.py:38-48 on channels-last rows."""
+        if self.training and random.random() <= self.stochastic_depth:
+            return rows
+        b, h, w = shape
+        m, c = rows.shape
+        film = self.encodings.film_rows(ctx.codes(c, h, w))
+        xf = torch.empty_like(rows)
+        ops.channelnorm_film(rows, film, ctx.slot, xf, b, h * w, c, self.norm.eps)
+        picks = self.ffn.pick()                                  # modules.py:35, drawn before any branch output is used
+        # y = conv(xf) + bias + res
+        y = torch.empty_like(rows)
+        g = c // 32
+        ops.gemm(xf, m, 32, 288, [self._conv_weight()], y, lda=c, ldw=288, biases=[self.conv.bias.detach()],
+                 addend=rows, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=32,
+                 groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32)
+        if self.attention_flag:
+            self.self_attention.forward_rows(xf, shape, addend=y, out=y)
+        self.ffn.forward_rows(xf, addend=y, out=y, picks=picks)
+        return y
+
+    def forward(self, x, t, c=None):
+        if c is not None and self.attention_flag:
+            raise NotImplementedError("cross-attention has no defined semantics in the reference (attention.py:92-98)")
+        rows, shape = to_rows(x)
+        out = self.forward_rows(rows, shape, TimeContext(t, shape[0], x.device))
+        return from_rows(out, shape)
+
+
+class SwinStack(nn.Module):
+    def __init__(self, channels, head_dim=32, window_size=6, num_blocks=2, attention=True):
+        super().__init__()
+        self.blocks = nn.ModuleList([])
+        for i in range(num_blocks):
+            shift = window_size // 2 if i % 2 == 0 else 0
+            flag_attn = attention if i >= num_blocks - 2 else False       # unet.py:57
+            self.blocks.append(SwinBlock(channels, head_dim, window_size, shift, attention=flag_attn))
+
+    def forward_rows(self, rows, shape, ctx):
+        for blk in self.blocks:
+            rows = blk.forward_rows(rows, shape, ctx)
+        return rows
+
+    def forward(self, x, t, c=None):
+        rows, shape = to_rows(x)
+        return from_rows(self.forward_rows(rows, shape, TimeContext(t, shape[0], x.device)), shape)
+
+
+class UNetBlock(nn.Module):
+    def __init__(self, stage, ch_conv):
+        super().__init__()
+        self.stage = stage
+        self.ch_conv = ch_conv
+
+
+class UNet(nn.Module):
+    def __init__(self, input_channels=8, stages=[3, 3, 9, 3], channels=[128, 256, 512, 1024], stem_size=1):
+        super().__init__()
+        if stem_size != 1:
+            raise NotImplementedError("only stem_size == 1 (the reference default) is implemented in HIP")
+        self.encoder_first = nn.Conv2d(input_channels, channels[0], stem_size, stem_size, 0)
+        self.decoder_last = nn.ConvTranspose2d(channels[0], input_channels, stem_size, stem_size, 0)
+        self.encoder_stages = nn.ModuleList([])
+        self.decoder_stages = nn.ModuleList([])
+        for i, (l, c) in enumerate(zip(stages, channels)):
+            last = i == len(stages) - 1
+            enc_stage = SwinStack(c, num_blocks=l, attention=False)
+            enc_ch_conv = nn.Identity() if last else nn.Sequential(nn.Conv2d(channels[i], channels[i + 1], 1, 1, 0), nn.AvgPool2d(kernel_size=2))
+            dec_stage = SwinStack(c, num_blocks=l)
+            dec_ch_conv = nn.Identity() if last else nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(channels[i + 1], channels[i], 1, 1, 0))
+            self.encoder_stages.append(UNetBlock(enc_stage, enc_ch_conv))
+            self.decoder_stages.insert(0, UNetBlock(dec_stage, dec_ch_conv))
+        self.input_channels = input_channels
+        self.channels = list(channels)
+        self._uniform_time = None          # set by DDPM.sample: every sample shares this timestep
+
+    def forward(self, x, time, condition=None):
+        b, cin, h, w = x.shape
+        dev = x.device
+        ctx = TimeContext(time, b, dev, uniform=self._uniform_time)
+        c0 = self.channels[0]
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x.contiguous().float(), w2d(self.encoder_first), self.encoder_first.bias.detach(), rows, b, cin, h * w, c0)
+        skips = []
+        n = len(self.encoder_stages)
+        for i, l in enumerate(self.encoder_stages):
+            rows = l.stage.forward_rows(rows, (b, h, w), ctx)
+            if i == n - 1:
+                skips.insert(0, None)                                  # unet.py:94-95 (adds the integer 0)
+            else:
+                skips.insert(0, rows)
+                conv = l.ch_conv[0]
+                cn = conv.weight.shape[0]
+                # AvgPool2d(Conv1x1(x)) == Conv1x1(AvgPool2d(x)) (both linear); pooled first: 4x fewer FLOPs
+                pooled = torch.empty(b * (h // 2) * (w // 2), rows.shape[1], device=dev, dtype=torch.float32)
+                ops.avgpool2(rows, pooled, b, h, w, rows.shape[1])
+                h, w = h // 2, w // 2
+                rows = torch.empty(b * h * w, cn, device=dev, dtype=torch.float32)
+                ops.gemm(pooled, b * h * w, cn, pooled.shape[1], [w2d(conv)], rows, biases=[conv.bias.detach()])
+        for i, (l, s) in enumerate(zip(self.decoder_stages, skips)):
+            if not isinstance(l.ch_conv, nn.Identity):
+                conv = l.ch_conv[1]
+                cn = conv.weight.shape[0]
+                # Conv1x1(nearest_up2(x)) == nearest_up2(Conv1x1(x)) exactly; the skip is added in the epilogue
+                up = torch.empty(b * 4 * h * w, cn, device=dev, dtype=torch.float32)
+                ops.gemm(rows, b * h * w, cn, rows.shape[1], [w2d(conv)], up, biases=[conv.bias.detach()],
+                         addend=s, o_mode=ops.O_UP2, out_hw=(h, w))
+                h, w = 2 * h, 2 * w
+                rows = up
+            elif s is not None:
+                raise RuntimeError("unexpected skip at an Identity ch_conv")
+            rows = l.stage.forward_rows(rows, (b, h, w), ctx)
+        out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
+        wl = self.decoder_last.weight.detach().reshape(c0, cin)         # ConvTranspose2d weight [C0, Cin, 1, 1]
+        ops.head_nchw(rows, wl, self.decoder_last.bias.detach(), out, b, c0, h * w, cin)
+        return out

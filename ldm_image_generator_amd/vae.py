@@ -1,0 +1,148 @@
+"""VAE decoder path (reference: vae.py:45-66,99-132), MI355X-native host side.
+
+``Decoder`` / ``DecoderStack`` / ``ResBlock`` / ``VAE.decode`` keep the reference's
+constructor arguments and its 50 ``state_dict`` keys (incl. the dead
+``output_layer``).  Every convolution is one launch of the fp32-MFMA GEMM family:
+dense 3x3 as implicit GEMM with fused bias + leaky_relu (+ residual),
+ConvTranspose2d(2,2) as one GEMM with a 2x2 scatter epilogue; ``to_rgb`` and the
+bilinear RGB accumulation are one fused HBM-bound kernel per stage.
+
+``Encoder``, ``VectorQuantizer``, ``Discriminator`` and ``VAE.calclate_loss`` (VAE
+training) are outside the hot path and are not provided.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import from_rows, to_rows, w2d
+
+
+class _PackedWeight:
+    """Cache of a re-laid-out weight, invalidated by in-place updates / device moves."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.key = None
+        self.val = None
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            self.key, self.val = key, self.fn(w.detach()).contiguous()
+        return self.val
+
+
+def _pack3x3(w):       # [Cout, Cin, 3, 3] -> [Cout][tap][Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1])
+
+
+def _pack_convt(w):    # ConvTranspose2d [Cin, Cout, 2, 2] -> [(dy, dx, co)][ci]
+    return w.permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0])
+
+
+def conv3x3_rows(rows, shape, conv, packed, slope=0.01, addend=None):
+    """lrelu(conv3x3(x) + bias) (+ addend) on channels-last rows."""
+    b, h, w = shape
+    cin, cout = conv.weight.shape[1], conv.weight.shape[0]
+    out = torch.empty(rows.shape[0], cout, device=rows.device, dtype=torch.float32)
+    ops.gemm(rows, rows.shape[0], cout, 9 * cin, [packed.get(conv.weight)], out, lda=cin, ldw=9 * cin,
+             biases=[conv.bias.detach()], act=ops.ACT_LRELU, slope=slope, addend=addend,
+             a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=cin)
+    return out
+
+
+class ResBlock(nn.Module):
+    """x + lrelu(c2(lrelu(c1(x))))  (vae.py:54-66)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.c1 = nn.Conv2d(channels, channels, 3, 1, 1)
+        self.c2 = nn.Conv2d(channels, channels, 3, 1, 1)
+        self._p1 = _PackedWeight(_pack3x3)
+        self._p2 = _PackedWeight(_pack3x3)
+
+    def forward_rows(self, rows, shape):
+        y = conv3x3_rows(rows, shape, self.c1, self._p1)
+        return conv3x3_rows(y, shape, self.c2, self._p2, addend=rows)
+
+    def forward(self, x):
+        rows, shape = to_rows(x)
+        return from_rows(self.forward_rows(rows, shape), shape)
+
+
+class DecoderStack(nn.Module):
+    def __init__(self, channels, num_layers, output_channels=3):
+        super().__init__()
+        if output_channels != 3:
+            raise NotImplementedError("the fused to_rgb kernel is specialised for 3 output channels")
+        self.layers = nn.Sequential(*[ResBlock(channels) for _ in range(num_layers)])
+        self.to_rgb = nn.Conv2d(channels, output_channels, 1, 1, 0)
+
+    def forward_rows(self, rows, shape, prev_rgb):
+        for blk in self.layers:
+            rows = blk.forward_rows(rows, shape)
+        b, h, w = shape
+        rgb = torch.empty(b, 3, h, w, device=rows.device, dtype=torch.float32)
+        ops.rgb_head(rows, w2d(self.to_rgb), self.to_rgb.bias.detach(), prev_rgb, rgb, b, h, w, rows.shape[1])
+        return rows, rgb
+
+    def forward(self, x):
+        rows, shape = to_rows(x)
+        rows, rgb = self.forward_rows(rows, shape, None)
+        return from_rows(rows, shape), rgb
+
+
+class Decoder(nn.Module):
+    def __init__(self, output_channels=3, latent_channels=8, channels=[512, 256, 128, 64], stages=[2, 2, 2, 2]):
+        super().__init__()
+        self.input_layer = nn.Conv2d(latent_channels, channels[0], 1, 1, 0)
+        self.output_layer = nn.Conv2d(channels[-1], output_channels, 1, 1, 0)       # dead weight in the reference too
+        self.stages = nn.ModuleList([DecoderStack(c, l, output_channels=output_channels) for c, l in zip(channels, stages)])
+        self.upsamples = nn.ModuleList([])
+        for i, c in enumerate(channels):
+            if i == 0:
+                self.upsamples.append(nn.Identity())
+            else:
+                self.upsamples.append(nn.ConvTranspose2d(channels[i - 1], c, 2, 2, 0))
+        self._up_packed = [_PackedWeight(_pack_convt) for _ in channels]
+
+    def forward(self, x):
+        """vae.py:122-132: z [B, latent, h, w] -> RGB [B, 3, 8h, 8w] (NCHW)."""
+        b, cz, h, w = x.shape
+        dev = x.device
+        c0 = self.input_layer.weight.shape[0]
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x.contiguous().float(), w2d(self.input_layer), self.input_layer.bias.detach(), rows, b, cz, h * w, c0)
+        rgb = None
+        for i, (up, stage) in enumerate(zip(self.upsamples, self.stages)):
+            if not isinstance(up, nn.Identity):
+                cin, cout = up.weight.shape[0], up.weight.shape[1]
+                fine = torch.empty(b * 4 * h * w, cout, device=dev, dtype=torch.float32)
+                ops.gemm(rows, b * h * w, 4 * cout, cin, [self._up_packed[i].get(up.weight)], fine,
+                         biases=[up.bias.detach()], ldo=cout, o_mode=ops.O_CONVT2X2, out_hw=(h, w), cout=cout)
+                rows = fine
+                h, w = 2 * h, 2 * w
+            rows, rgb = stage.forward_rows(rows, (b, h, w), rgb)
+        return rgb
+
+
+class VAE(nn.Module):
+    """vae.py:30-52 restricted to the sampling path (decode)."""
+
+    def __init__(self, encoder, decoder, quantizer):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.quantizer = quantizer
+
+    @torch.no_grad()
+    def decode(self, z):
+        return self.decoder(z)
+
+
+def to_uint8_images(img):
+    """sample_ldm.py:75-77 on the device: [B,3,H,W] float -> [B,H,W,3] uint8 (truncation)."""
+    b, c, h, w = img.shape
+    out = torch.empty(b, h, w, c, device=img.device, dtype=torch.uint8)
+    ops.to_uint8_hwc(img.contiguous(), out, b, c, h * w)
+    return out

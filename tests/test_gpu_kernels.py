@@ -1,0 +1,254 @@
+"""Parity of each HIP entry point (through the C ABI) against a CPU statement of the
+same op.  Tolerances (fp32 MFMA == fmaf chain; reference self-noise ~5e-7):
+GEMM-family kernels rel-L2 <= 1e-5 against an fp64 evaluation, elementwise kernels
+bit-exact where the reference's op order is reproduced exactly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import T, load_golden, rel_l2
+from oracle import ldm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops(gpu_device):
+    from ldm_image_generator_amd import ops as _ops
+    from ldm_image_generator_amd import _lib
+    assert _lib.load().ldm_device_ok() == 1, "device 0 is not gfx950"
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 32, 32), (37, 64, 96), (128, 128, 64), (300, 256, 512), (16, 384, 2048),
+                                   (1000, 96, 160), (129, 128, 32)])
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_gemm_plain(ops, gpu_device, M, N, K, act):
+    a, w, b, add = rnd(M, K), rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2), rnd(M, N, seed=3)
+    out = torch.empty(M, N, device=gpu_device)
+    ops.gemm(a.cuda(), M, N, K, [w.cuda()], out, biases=[b.cuda()], addend=add.cuda(),
+             act=ops.ACT_RELU if act == "relu" else ops.ACT_NONE)
+    ref = a.double() @ w.double().t() + b.double()
+    if act == "relu":
+        ref = torch.relu(ref)
+    ref = ref + add.double()
+    assert rel_l2(out.cpu(), ref) < KTOL
+
+
+@pytest.mark.parametrize("M,C", [(50, 32), (260, 64), (257, 128), (64, 256)])
+def test_gemm_gate_and_ksegments(ops, gpu_device, M, C):
+    """ReGLU sum of 3 experts: gated GEMM with N-segments, then GEMM with K-segments (modules.py:15,36)."""
+    x = rnd(M, C)
+    wa = [rnd(C, C, seed=10 + i, scale=C ** -0.5) for i in range(3)]
+    wb = [rnd(C, C, seed=20 + i, scale=C ** -0.5) for i in range(3)]
+    wc = [rnd(C, C, seed=30 + i, scale=C ** -0.5) for i in range(3)]
+    ba = [rnd(C, seed=40 + i) for i in range(3)]
+    bb = [rnd(C, seed=50 + i) for i in range(3)]
+    bc = [rnd(C, seed=60 + i) for i in range(3)]
+    res = rnd(M, C, seed=70)
+    dev = lambda ts: [t.cuda() for t in ts]
+    hid = torch.empty(M, 3 * C, device=gpu_device)
+    ops.gemm(x.cuda(), M, 3 * C, C, dev(wa), hid, weights2=dev(wb), biases=dev(ba), biases2=dev(bb), act=ops.ACT_GATE)
+    xd = x.double()
+    href = torch.cat([(xd @ wa[i].double().t() + ba[i].double()) * torch.relu(xd @ wb[i].double().t() + bb[i].double())
+                      for i in range(3)], dim=1)
+    assert rel_l2(hid.cpu(), href) < KTOL
+    out = res.cuda().clone()
+    ops.gemm(hid, M, C, 3 * C, dev(wc), out, biases=dev(bc), seg_mode=ops.SEG_K, addend=out)
+    ref = sum(href[:, i * C:(i + 1) * C] @ wc[i].double().t() + bc[i].double() for i in range(3)) + res.double()
+    assert rel_l2(out.cpu(), ref) < KTOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 32, 32), (1, 16, 16, 64, 128), (3, 8, 8, 96, 64), (1, 33, 9, 32, 96)])
+def test_conv3x3_dense(ops, gpu_device, B, H, W, Cin, Cout):
+    x = rnd(B, Cin, H, W)
+    w = rnd(Cout, Cin, 3, 3, seed=1, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=2)
+    res = rnd(B, Cout, H, W, seed=3)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda()
+    add = res.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()
+    out = torch.empty(B * H * W, Cout, device=gpu_device)
+    ops.gemm(rows, B * H * W, Cout, 9 * Cin, [wp], out, lda=Cin, ldw=9 * Cin, biases=[b.cuda()], act=ops.ACT_LRELU,
+             slope=0.01, addend=add, a_mode=ops.A_CONV3X3, conv_hw=(H, W), cin=Cin)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01) + res.double()
+    got = out.cpu().reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < KTOL
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 6, 9, 64), (1, 32, 32, 128), (2, 4, 4, 256), (1, 7, 5, 32)])
+def test_grouped_conv3x3(ops, gpu_device, B, H, W, C):
+    x = rnd(B, C, H, W)
+    w = rnd(C, 32, 3, 3, seed=1, scale=288 ** -0.5)
+    b = rnd(C, seed=2)
+    res = rnd(B, C, H, W, seed=3)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
+    add = res.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(C, 288).contiguous().cuda()
+    out = torch.empty(B * H * W, C, device=gpu_device)
+    ops.gemm(rows, B * H * W, 32, 288, [wp], out, lda=C, ldw=288, biases=[b.cuda()], addend=add, ldadd=C, ldo=C,
+             a_mode=ops.A_CONV3X3, conv_hw=(H, W), cin=32, groups=C // 32, a_gstride=32, w_gstride=32 * 288, o_gstride=32)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1, groups=C // 32) + res.double()
+    got = out.cpu().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < KTOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 3, 5, 64, 32), (1, 8, 8, 128, 64)])
+def test_conv_transpose_2x2(ops, gpu_device, B, H, W, Cin, Cout):
+    x = rnd(B, Cin, H, W)
+    w = rnd(Cin, Cout, 2, 2, seed=1, scale=Cin ** -0.5)
+    b = rnd(Cout, seed=2)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda()
+    wp = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).contiguous().cuda()
+    out = torch.empty(B * 4 * H * W, Cout, device=gpu_device)
+    ops.gemm(rows, B * H * W, 4 * Cout, Cin, [wp], out, biases=[b.cuda()], ldo=Cout, o_mode=ops.O_CONVT2X2,
+             out_hw=(H, W), cout=Cout)
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    got = out.cpu().reshape(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < KTOL
+
+
+def test_upsample_conv_skip(ops, gpu_device):
+    """unet.py:85,101: Conv1x1(nearest_up2(x)) + skip, computed at the coarse grid and replicated."""
+    B, H, W, Cin, Cout = 2, 4, 3, 64, 32
+    x, w, b, skip = rnd(B, Cin, H, W), rnd(Cout, Cin, seed=1, scale=Cin ** -0.5), rnd(Cout, seed=2), rnd(B, Cout, 2 * H, 2 * W, seed=3)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda()
+    srows = skip.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda()
+    out = torch.empty(B * 4 * H * W, Cout, device=gpu_device)
+    ops.gemm(rows, B * H * W, Cout, Cin, [w.cuda()], out, biases=[b.cuda()], addend=srows, o_mode=ops.O_UP2, out_hw=(H, W))
+    up = F.interpolate(x.double(), scale_factor=2, mode="nearest")
+    ref = F.conv2d(up, w.double().reshape(Cout, Cin, 1, 1), b.double()) + skip.double()
+    got = out.cpu().reshape(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < KTOL
+
+
+@pytest.mark.parametrize("B,HW,C", [(2, 35, 32), (3, 16, 96), (2, 64, 128), (1, 9, 512), (2, 4, 1024)])
+def test_channelnorm_film(ops, gpu_device, B, HW, C):
+    x = rnd(B * HW, C) * 3 + 0.5
+    film = rnd(2 * HW, 2 * C, seed=1)
+    slot = torch.tensor([1, 0, 1][:B], dtype=torch.int32)
+    out = torch.empty(B * HW, C, device=gpu_device)
+    ops.channelnorm_film(x.cuda(), film.cuda(), slot.cuda(), out, B, HW, C, 1e-4)
+    xn = O.channel_norm(x.reshape(B, HW, C).permute(0, 2, 1).reshape(B, C, HW, 1)).reshape(B, C, HW).permute(0, 2, 1)
+    f = film.reshape(2, HW, 2 * C)[slot.long()]
+    ref = xn * f[:, :, :C] + f[:, :, C:]
+    assert rel_l2(out.cpu().reshape(B, HW, C), ref) < 2e-6
+
+
+def test_sincos_embed_matches_reference_tables(gpu_device):
+    from ldm_image_generator_amd import sinusoidal
+    g = load_golden("tables")
+    steps = T(g["te_steps"]).long()
+    for c, h, w in [(32, 7, 5), (128, 32, 32), (1024, 4, 4)]:
+        emb = sinusoidal.embed(steps.cuda(), h, w, c).cpu().reshape(50, h * w, 2 * c)
+        pe = T(g["pe_%d_%d_%d" % (c, h, w)]).permute(1, 2, 0).reshape(h * w, c)
+        assert (emb[0, :, :c] - pe).abs().max() < 2e-6
+        assert torch.equal(emb[0, :, :c], emb[49, :, :c])
+        if "te_%d" % c in g:
+            te = T(g["te_%d" % c])
+            # arguments reach ~3.1e3 rad: one ulp of the argument is 2.4e-4
+            assert (emb[:, 0, c:] - te).abs().max() < 5e-4
+            assert (emb[:, 0, c:] - te).abs().mean() < 2e-5
+            assert torch.equal(emb[:, 0, c:], emb[:, h * w - 1, c:])
+
+
+def test_avgpool_stem_head_transposes(ops, gpu_device):
+    B, H, W, C = 2, 6, 4, 64
+    x = rnd(B, C, H, W)
+    rows = torch.empty(B * H * W, C, device=gpu_device)
+    ops.nchw_to_nhwc(x.cuda(), rows, B, C, H * W)
+    assert torch.equal(rows.cpu(), x.permute(0, 2, 3, 1).reshape(-1, C))
+    back = torch.empty(B, C, H, W, device=gpu_device)
+    ops.nhwc_to_nchw(rows, back, B, C, H * W)
+    assert torch.equal(back.cpu(), x)
+    pooled = torch.empty(B * (H // 2) * (W // 2), C, device=gpu_device)
+    ops.avgpool2(rows, pooled, B, H, W, C)
+    ref = F.avg_pool2d(x, 2).permute(0, 2, 3, 1).reshape(-1, C)
+    assert rel_l2(pooled.cpu(), ref) < 1e-6
+    for cin in (3, 8):
+        xi = rnd(B, cin, H, W, seed=4)
+        w, b = rnd(C, cin, seed=5), rnd(C, seed=6)
+        out = torch.empty(B * H * W, C, device=gpu_device)
+        ops.stem_nchw(xi.cuda(), w.cuda(), b.cuda(), out, B, cin, H * W, C)
+        ref = (torch.einsum("oc,nchw->nhwo", w.double(), xi.double()) + b.double()).reshape(-1, C)
+        assert rel_l2(out.cpu(), ref) < 1e-6
+        wt, bt = rnd(C, cin, seed=7), rnd(cin, seed=8)
+        o2 = torch.empty(B, cin, H, W, device=gpu_device)
+        ops.head_nchw(rows, wt.cuda(), bt.cuda(), o2, B, C, H * W, cin)
+        ref = torch.einsum("co,nchw->nohw", wt.double(), x.double()) + bt.double().reshape(1, -1, 1, 1)
+        assert rel_l2(o2.cpu(), ref) < 1e-6
+    # C0 > 128 exercises the chunked head
+    C2 = 320
+    x2 = rnd(B, C2, H, W, seed=9)
+    r2 = x2.permute(0, 2, 3, 1).reshape(-1, C2).contiguous().cuda()
+    wt, bt = rnd(C2, 8, seed=10), rnd(8, seed=11)
+    o2 = torch.empty(B, 8, H, W, device=gpu_device)
+    ops.head_nchw(r2, wt.cuda(), bt.cuda(), o2, B, C2, H * W, 8)
+    ref = torch.einsum("co,nchw->nohw", wt.double(), x2.double()) + bt.double().reshape(1, -1, 1, 1)
+    assert rel_l2(o2.cpu(), ref) < 1e-6
+
+
+def test_ddim_update_bit_exact(ops, gpu_device):
+    _, _, alpha = O.schedule_tables()
+    x, e, nz = rnd(2, 8, 16, 16) * 50, rnd(2, 8, 16, 16, seed=1) * 7, rnd(2, 8, 16, 16, seed=2)
+    for (t, tn, eta) in [(999, 978, 0.0), (20, 0, 0.0), (0, 0, 0.0), (489, 468, 0.5)]:
+        sigma, s1, s2, s3, s4 = O.ddim_coefficients(alpha, t, tn, eta)
+        x_t0 = (x - s1 * e) / s2
+        ref = x_t0 if t == 0 else s3 * x_t0 + s4 * e + sigma * nz
+        got = x.cuda().clone()
+        ops.ddim_update(got, e.cuda(), nz.cuda(), float(s1), float(s2), float(s3), float(s4), float(sigma), t == 0)
+        assert torch.equal(got.cpu(), ref), (t, tn, eta)
+
+
+def test_qsample_bit_exact(ops, gpu_device):
+    _, alpha_bar, _ = O.schedule_tables()
+    x, e = rnd(3, 8, 8, 8), rnd(3, 8, 8, 8, seed=1)
+    t = torch.tensor([1, 500, 999])
+    ab = alpha_bar[t].reshape(-1, 1, 1, 1)
+    ref = torch.sqrt(ab) * x + torch.sqrt(1 - ab) * e
+    out = torch.empty(3, 8, 8, 8, device=gpu_device)
+    ops.qsample(x.cuda(), e.cuda(), torch.sqrt(alpha_bar[t]).cuda(), torch.sqrt(1 - alpha_bar[t]).cuda(), out)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("C", [32, 64, 512])
+def test_rgb_head_and_bilinear(ops, gpu_device, C):
+    B, H, W = 2, 6, 10
+    x = rnd(B, C, H, W)
+    w, b = rnd(3, C, seed=1, scale=C ** -0.5), rnd(3, seed=2)
+    prev = rnd(B, 3, H // 2, W // 2, seed=3)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
+    out = torch.empty(B, 3, H, W, device=gpu_device)
+    ops.rgb_head(rows, w.cuda(), b.cuda(), None, out, B, H, W, C)
+    rgb = F.conv2d(x.double(), w.double().reshape(3, C, 1, 1), b.double())
+    assert rel_l2(out.cpu(), rgb) < 2e-6
+    ops.rgb_head(rows, w.cuda(), b.cuda(), prev.cuda(), out, B, H, W, C)
+    ref = F.interpolate(prev.double(), scale_factor=2, mode="bilinear") + rgb
+    assert rel_l2(out.cpu(), ref) < 2e-6
+
+
+def test_to_uint8(ops, gpu_device):
+    img = rnd(2, 3, 9, 7) * 0.8
+    img[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, 3.0, -2.0])
+    out = torch.empty(2, 9, 7, 3, dtype=torch.uint8, device=gpu_device)
+    ops.to_uint8_hwc(img.cuda(), out, 2, 3, 63)
+    assert np.array_equal(out.cpu().numpy(), O.to_uint8_hwc(img))
+
+
+def test_errors_are_reported_not_thrown(ops, gpu_device):
+    from ldm_image_generator_amd._lib import LdmHipError, LdmHipUnavailable
+    a = torch.zeros(4, 40, device=gpu_device)
+    with pytest.raises(LdmHipError):
+        ops.gemm(a, 4, 32, 40, [torch.zeros(32, 40, device=gpu_device)], torch.zeros(4, 32, device=gpu_device))   # K % 32
+    with pytest.raises(LdmHipUnavailable):
+        ops.avgpool2(torch.zeros(1, 4, 4, 8), torch.zeros(1, 2, 2, 8), 1, 4, 4, 8)                                   # CPU tensor

@@ -1,0 +1,190 @@
+"""The drop-in modules (UNet / WindowAttention / SwinBlock / Decoder / DDPM.sample) on the
+GPU against the golden vectors produced by the imported reference, and against the CPU
+oracle on fresh inputs.  Stated fp32 tolerances: module rel-L2 <= 1e-5,
+UNet forward <= 2e-5, 50-step latents / decoded images rel-L2 <= 1e-4, max-abs/absmax <= 1e-3."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, decode_trace, load_golden, max_rel, rel_l2
+from oracle import ldm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(input_channels=8, stages=[1, 2, 3, 2], channels=[32, 64, 96, 128])
+
+
+def formula(module, gain=1.0):
+    from ldm_image_generator_amd import synth
+    module.load_state_dict(synth.fill_state_dict(module.state_dict(), gain=gain))
+    return module.cuda()
+
+
+@pytest.fixture(scope="module")
+def tiny_unet(gpu_device):
+    from ldm_image_generator_amd.unet import UNet
+    return formula(UNet(**TINY))
+
+
+@pytest.fixture(scope="module")
+def full_unet(gpu_device):
+    from ldm_image_generator_amd.unet import UNet
+    return formula(UNet())
+
+
+def test_small_modules(gpu_device):
+    from ldm_image_generator_amd.modules import ChannelNorm, RandomMoE
+    from ldm_image_generator_amd.unet import Encodings
+    g = load_golden("channel_norm")
+    assert rel_l2(ChannelNorm(32)(T(g["x"]).cuda()).cpu(), T(g["y"])) < 2e-6
+    g = load_golden("encodings")
+    enc = formula(Encodings(32))
+    assert rel_l2(enc(T(g["x"]).cuda(), T(g["t"]).cuda()).cpu(), T(g["y"])) < 1e-5
+    g = load_golden("random_moe")
+    moe = formula(RandomMoE(32))
+    x = T(g["x"]).cuda()
+    assert rel_l2(moe.general(x).cpu(), T(g["general"])) < 1e-5
+    for seed in (0, 1, 7):
+        random.seed(seed)
+        assert rel_l2(moe(x).cpu(), T(g["y_%d" % seed])) < 1e-5
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_window_attention_all_geometries(gpu_device, shift):
+    from ldm_image_generator_amd.attention import WindowAttention
+    g = load_golden("window_attention")
+    wa = formula(WindowAttention(64, n_heads=2, window_size=6, shift=shift), gain=2.0)
+    for hw in [(8, 8), (16, 16), (12, 12), (7, 9), (4, 4), (6, 6), (32, 32)]:
+        y = wa(T(g["x_%d_%d" % hw]).cuda()).cpu()
+        assert rel_l2(y, T(g["y_s%d_%d_%d" % (shift, hw[0], hw[1])])) < 1e-5, hw
+
+
+@pytest.mark.parametrize("attn,shift", [(1, 3), (1, 0), (0, 0)])
+def test_swin_block(gpu_device, attn, shift):
+    from ldm_image_generator_amd.unet import SwinBlock
+    g = load_golden("swin_block_a%d_s%d" % (attn, shift))
+    blk = formula(SwinBlock(64, shift=shift, attention=bool(attn)))
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    blk.eval()
+    random.seed(5)
+    assert rel_l2(blk(x, t).cpu(), T(g["y_eval"])) < 1e-5
+    blk.train()
+    for seed in (0, 3):
+        random.seed(seed)
+        assert rel_l2(blk(x, t).cpu(), T(g["y_train_%d" % seed])) < 1e-5
+
+
+def test_unet_tiny_eval_and_train_rng(tiny_unet):
+    g = load_golden("unet_tiny")
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    tiny_unet.eval()
+    random.seed(11)
+    assert rel_l2(tiny_unet(x, t).cpu(), T(g["y_eval"])) < 2e-5
+    after = random.random()
+    random.seed(11)
+    for _ in range(len(decode_trace(g["trace_eval"]))):
+        random.sample(range(4), 2)
+    assert after == random.random()            # consumed Python's RNG exactly like the reference
+    tiny_unet.train()
+    for seed in (0, 1):
+        random.seed(seed)
+        assert rel_l2(tiny_unet(x, t).cpu(), T(g["y_train_%d" % seed])) < 2e-5
+
+
+def test_unet_pixel_space_3ch(gpu_device):
+    from ldm_image_generator_amd.unet import UNet
+    g = load_golden("unet_tiny3")
+    net = formula(UNet(input_channels=3, stages=[1, 2], channels=[32, 64])).eval()
+    random.seed(2)
+    assert rel_l2(net(T(g["x"]).cuda(), T(g["t"]).cuda()).cpu(), T(g["y_eval"])) < 2e-5
+
+
+def test_unet_full_size(full_unet):
+    g = load_golden("unet_full")
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    with torch.no_grad():
+        full_unet.eval()
+        random.seed(0)
+        assert rel_l2(full_unet(x, t).cpu(), T(g["y_eval"])) < 2e-5
+        full_unet.train()
+        random.seed(0)
+        assert rel_l2(full_unet(x, t).cpu(), T(g["y_train_0"])) < 2e-5
+
+
+def test_ddim_sample_tiny(tiny_unet):
+    from ldm_image_generator_amd.ddpm import DDPM
+    g = load_golden("sample_tiny")
+    d = DDPM(model=tiny_unet)
+    assert list(d.state_dict().keys())[0].startswith("model.") and len(d.state_dict()) == len(tiny_unet.state_dict())
+    for mode in ("train", "eval"):
+        tiny_unet.train(mode == "train")
+        for steps in (5, 50):
+            x0 = d.sample((2, 8, 32, 32), seed=0, num_steps=steps, x_init=T(g["xT"]), progress=False).cpu()
+            ref = T(g["x0_%s_%d" % (mode, steps)])
+            assert rel_l2(x0, ref) < 1e-4 and max_rel(x0, ref) < 1e-3, (mode, steps)
+
+
+def test_ddim_sample_full_size_50_steps(full_unet):
+    from ldm_image_generator_amd.ddpm import DDPM
+    g = load_golden("sample_full")
+    d = DDPM(model=full_unet)
+    full_unet.train()
+    x0 = d.sample((1, 8, 32, 32), seed=0, num_steps=50, x_init=T(g["xT"]), progress=False).cpu()
+    ref = T(g["x0_train_50"])
+    assert rel_l2(x0, ref) < 1e-4 and max_rel(x0, ref) < 1e-3
+    full_unet.eval()
+    x0 = d.sample((1, 8, 32, 32), seed=0, num_steps=3, x_init=T(g["xT"]), progress=False).cpu()
+    assert rel_l2(x0, T(g["x0_eval_3"])) < 1e-4
+
+
+def test_batched_sampling_equals_per_sample(tiny_unet):
+    """Samples never interact: a batch equals its slices run alone."""
+    from ldm_image_generator_amd.ddpm import DDPM
+    d = DDPM(model=tiny_unet)
+    tiny_unet.eval()
+    xT = torch.randn(4, 8, 32, 32, generator=torch.Generator().manual_seed(5))
+    full = d.sample((4, 8, 32, 32), seed=1, num_steps=4, x_init=xT, progress=False).cpu()
+    for lo in (0, 2):
+        part = d.sample((2, 8, 32, 32), seed=1, num_steps=4, x_init=xT[lo:lo + 2], progress=False).cpu()
+        assert torch.equal(part, full[lo:lo + 2])
+
+
+def test_decoder_tiny_and_resblock(gpu_device):
+    from ldm_image_generator_amd.vae import Decoder, ResBlock
+    g = load_golden("res_block")
+    rb = formula(ResBlock(32))
+    assert rel_l2(rb(T(g["x"]).cuda()).cpu(), T(g["y"])) < 1e-5
+    g = load_golden("decoder_tiny")
+    dec = formula(Decoder(channels=[64, 32, 32], stages=[1, 2, 1]))
+    assert rel_l2(dec(T(g["z"]).cuda()).cpu(), T(g["y"])) < 1e-5
+
+
+def test_decoder_full_size_and_uint8(gpu_device):
+    from ldm_image_generator_amd.vae import Decoder, to_uint8_images
+    g = load_golden("decoder_full")
+    dec = formula(Decoder())
+    with torch.no_grad():
+        y = dec(T(g["z"]).cuda())
+    yc = y.cpu()
+    assert rel_l2(yc[:, :, ::4, ::4], T(g["y_sub"])) < 1e-5
+    assert rel_l2(yc[:, :, 100:104, :], T(g["y_rows"])) < 1e-5
+    assert abs(float(yc.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
+    u8 = to_uint8_images(y).cpu().numpy()[0]
+    diff = np.abs(u8[100:104].astype(int) - g["u8_rows"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-2
+
+
+def test_unet_vs_oracle_fresh_inputs_per_sample_t(tiny_unet):
+    """Per-sample timesteps (training-style), oracle evaluated live on the host."""
+    from ldm_image_generator_amd import synth
+    sd = synth.fill_state_dict(tiny_unet.state_dict())
+    x = torch.randn(5, 8, 32, 32, generator=torch.Generator().manual_seed(9))
+    t = torch.tensor([7, 999, 7, 123, 500])
+    tiny_unet.train()
+    random.seed(21)
+    y = tiny_unet(x.cuda(), t.cuda()).cpu()
+    random.seed(21)
+    ref = O.unet_forward(sd, x, t, stages=TINY["stages"], channels=TINY["channels"], training=True)
+    assert rel_l2(y, ref) < 2e-5
