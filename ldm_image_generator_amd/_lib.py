@@ -83,6 +83,10 @@ def load():
         raise LdmHipUnavailable(
             "%s is missing: build it with `python -m ldm_image_generator_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Streams and device pointers
+    # are shared with torch, so both must live in ONE HIP runtime: make sure torch's copy is the
+    # one already mapped before our library's NEEDED entry is resolved.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:          # e.g. libamdhip64 not present
