@@ -92,10 +92,16 @@ typedef struct ldm_gemm_desc {
     int          OH, OW;     /* CONVT2X2 / UP2: coarse grid, M == B*OH*OW        */
     int          Cout;       /* CONVT2X2: N == 4*Cout, n = (dy*2+dx)*Cout + co   */
 
-    int          groups;     /* >=1; grouped conv: per-group offsets below       */
-    long long    a_gstride;  /* floats added to the A column offset per group    */
-    long long    w_gstride;  /* floats added to every w[s] per group             */
-    long long    o_gstride;  /* floats added to out/addend/bias column per group */
+    int          groups;     /* >=1; group g runs on grid.y with the offsets below */
+    long long    a_gstride;  /* floats added to a per group                       */
+    long long    w_gstride;  /* floats added to every w[s] / w2[s] per group      */
+    long long    o_gstride;  /* floats added to out and addend per group          */
+    long long    b_gstride;  /* floats added to every bias pointer per group      */
+    /* pointer-table mode (independent layers batched into one launch, e.g. the
+     * Encodings MLPs of all SwinBlocks of one UNet level): DEVICE arrays of
+     * `groups` pointers that replace w[0] / bias[0] for group g (nseg must be 1). */
+    const float *const *w_table;
+    const float *const *bias_table;
 } ldm_gemm_desc;
 
 int         ldm_version(void);

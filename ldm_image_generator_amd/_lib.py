@@ -43,6 +43,7 @@ class GemmDesc(ctypes.Structure):
         ("o_mode", ctypes.c_int), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("Cout", ctypes.c_int),
         ("groups", ctypes.c_int),
         ("a_gstride", ctypes.c_longlong), ("w_gstride", ctypes.c_longlong), ("o_gstride", ctypes.c_longlong),
+        ("b_gstride", ctypes.c_longlong), ("w_table", c_fp), ("bias_table", c_fp),
     ]
 
 

@@ -148,19 +148,38 @@ __global__ void avgpool2_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__
     out[idx] = o;
 }
 
-// stem: NCHW -> NHWC, 1x1 conv with tiny K
-__global__ void stem_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                            float *__restrict__ out, long long M, int Cin, int HW, int C0)
+// stem: NCHW -> NHWC, 1x1 conv with tiny K.  W^T lives in LDS ([Cin][C0], read as conflict-free
+// float4 rows); a thread owns 4 consecutive output channels and walks pixels; x values are
+// wave-broadcast loads; stores are full 16-B, row-contiguous.
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ out, long long M,
+                                                   int Cin, int HW, int C0, int pix_per_block)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * C0) return;
-    const int n = (int)(idx % C0);
-    const long long m = idx / C0;
-    const long long b = m / HW;
-    const int pix = (int)(m - b * HW);
-    float acc = 0.f;
-    for (int ci = 0; ci < Cin; ++ci) acc = fmaf(x[(b * Cin + ci) * HW + pix], w[n * Cin + ci], acc);
-    out[idx] = acc + (bias ? bias[n] : 0.f);
+    extern __shared__ __attribute__((aligned(16))) float wt[];      // [Cin][C0]
+    const int t = threadIdx.x;
+    for (int i = t; i < Cin * C0; i += 256) {
+        const int n = i / Cin, ci = i - n * Cin;
+        wt[ci * C0 + n] = w[i];
+    }
+    __syncthreads();
+    const int n4n = C0 >> 2;
+    const long long m0 = (long long)blockIdx.x * pix_per_block;
+    for (int i = t; i < pix_per_block * n4n; i += 256) {
+        const int pl = i / n4n, n4 = i - pl * n4n;
+        const long long m = m0 + pl;
+        if (m >= M) break;
+        const long long b = m / HW;
+        const int pix = (int)(m - b * HW);
+        f32x4 acc = bias ? *(const f32x4 *)(bias + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *xp = x + b * Cin * HW + pix;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xp[(long long)ci * HW];
+            const f32x4 wv = *(const f32x4 *)(wt + ci * C0 + 4 * n4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+        }
+        *(f32x4 *)(out + m * C0 + 4 * n4) = acc;
+    }
 }
 
 // head: NHWC -> NCHW, ConvTranspose 1x1 (w [C0, Cin]); 64 pixels per block, C0 walked in chunks of 128
@@ -378,9 +397,12 @@ extern "C" int ldm_avgpool2_f32(const float *x, float *out, int B, int H, int W,
 extern "C" int ldm_stem_nchw_f32(const float *x, const float *w, const float *bias, float *out, int B, int Cin, int HW, int C0, void *stream)
 {
     LDM_REQUIRE(x && w && out, "ldm_stem_nchw_f32: null pointer");
-    LDM_REQUIRE(B > 0 && Cin > 0 && HW > 0 && C0 > 0, "ldm_stem_nchw_f32: bad shape");
+    LDM_REQUIRE(B > 0 && Cin > 0 && HW > 0 && C0 >= 4 && C0 % 4 == 0, "ldm_stem_nchw_f32: bad shape (C0 %% 4 == 0)");
+    LDM_REQUIRE((size_t)Cin * C0 * sizeof(float) <= 64 * 1024, "ldm_stem_nchw_f32: Cin*C0 too large for the LDS weight tile");
+    LDM_REQUIRE(ldm_aligned16(out) && (!bias || ldm_aligned16(bias)), "ldm_stem_nchw_f32: unaligned pointer");
     const long long M = (long long)B * HW;
-    hipLaunchKernelGGL(stem_kernel, dim3(blocks_for(M * C0, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, M, Cin, HW, C0);
+    const int ppb = 64;
+    hipLaunchKernelGGL(stem_kernel, dim3(blocks_for(M, ppb)), dim3(256), (size_t)Cin * C0 * sizeof(float), (hipStream_t)stream, x, w, bias, out, M, Cin, HW, C0, ppb);
     LDM_CHECK_LAUNCH("ldm_stem_nchw_f32");
     return LDM_OK;
 }

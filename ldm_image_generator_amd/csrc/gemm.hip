@@ -43,7 +43,9 @@ struct GemmP {
     float *out;
     long long ldo;
     int o_mode, OH, OW, Cout;
-    long long a_gstride, w_gstride, o_gstride;
+    long long a_gstride, w_gstride, o_gstride, b_gstride;
+    const float *const *w_table;
+    const float *const *bias_table;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
             seg = (kt << 5) / p.seg_len;
             kcol -= (long long)seg * p.seg_len;
         }
-        const float *wa = p.w[seg] + g * p.w_gstride + kcol + chunk * 4;
+        const float *wa = (p.w_table ? p.w_table[g] : p.w[seg] + g * p.w_gstride) + kcol + chunk * 4;
         const float *wb = GATE ? p.w2[seg] + g * p.w_gstride + kcol + chunk * 4 : nullptr;
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
@@ -175,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
 
     // ---- epilogue ----------------------------------------------------------
     const long long gcol = g * p.o_gstride;
+    const long long gb = g * p.b_gstride;
+    const float *tbias = p.bias_table ? p.bias_table[g] : nullptr;
     float b1[TN], b2[TN];
     int q4[TN];
     long long ocol[TN];
@@ -192,14 +196,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
         ocol[jn] = gcol + co;
         b1[jn] = 0.f;
         b2[jn] = 0.f;
-        if (p.seg_mode == LDM_SEG_K) {
-            if (p.bias[0]) b1[jn] += p.bias[0][gcol + bidx];
-            if (p.nseg > 1 && p.bias[1]) b1[jn] += p.bias[1][gcol + bidx];
-            if (p.nseg > 2 && p.bias[2]) b1[jn] += p.bias[2][gcol + bidx];
-            if (p.nseg > 3 && p.bias[3]) b1[jn] += p.bias[3][gcol + bidx];
+        if (tbias) {
+            b1[jn] = tbias[bidx];
+        } else if (p.seg_mode == LDM_SEG_K) {
+            if (p.bias[0]) b1[jn] += p.bias[0][gb + bidx];
+            if (p.nseg > 1 && p.bias[1]) b1[jn] += p.bias[1][gb + bidx];
+            if (p.nseg > 2 && p.bias[2]) b1[jn] += p.bias[2][gb + bidx];
+            if (p.nseg > 3 && p.bias[3]) b1[jn] += p.bias[3][gb + bidx];
         } else {
-            if (p.bias[seg_n]) b1[jn] = p.bias[seg_n][gcol + bidx];
-            if (GATE && p.bias2[seg_n]) b2[jn] = p.bias2[seg_n][gcol + bidx];
+            if (p.bias[seg_n]) b1[jn] = p.bias[seg_n][gb + bidx];
+            if (GATE && p.bias2[seg_n]) b2[jn] = p.bias2[seg_n][gb + bidx];
         }
     }
 #pragma unroll
@@ -340,7 +346,8 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
     LDM_REQUIRE(seg_len > 0 && seg_len % 32 == 0 && (long long)seg_len * d->nseg == seg_total,
                 "ldm_gemm_f32: segments (%d x %d) do not cover %d", d->nseg, seg_len, seg_total);
     LDM_REQUIRE(!(gate && d->seg_mode == LDM_SEG_K && d->nseg > 1), "ldm_gemm_f32: GATE with K-segments is not supported");
-    for (int s = 0; s < d->nseg; ++s) {
+    if (d->w_table) LDM_REQUIRE(d->nseg == 1 && !gate, "ldm_gemm_f32: pointer-table mode needs nseg == 1 and no GATE");
+    for (int s = 0; s < d->nseg && !d->w_table; ++s) {
         LDM_REQUIRE(d->w[s] && ldm_aligned16(d->w[s]), "ldm_gemm_f32: weight segment %d null/unaligned", s);
         if (gate) LDM_REQUIRE(d->w2[s] && ldm_aligned16(d->w2[s]), "ldm_gemm_f32: gate weight segment %d null/unaligned", s);
     }
@@ -369,7 +376,8 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
         LDM_REQUIRE(d->OH > 0 && d->OW > 0 && d->M % (d->OH * d->OW) == 0, "ldm_gemm_f32: scatter output needs M %% (OH*OW) == 0");
         if (d->o_mode == LDM_O_CONVT2X2) LDM_REQUIRE(d->Cout > 0 && d->N == 4 * d->Cout, "ldm_gemm_f32: convT2x2 needs N == 4*Cout");
     }
-    p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.o_gstride = d->o_gstride;
+    p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.o_gstride = d->o_gstride; p.b_gstride = d->b_gstride;
+    p.w_table = d->w_table; p.bias_table = d->bias_table;
 
     hipStream_t st = (hipStream_t)stream;
     ProfRec *rec = nullptr;

@@ -40,7 +40,8 @@ def _opt(t, name, dtype=torch.float32):
 
 def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=None, biases2=None, ldw=None,
          seg_mode=SEG_N, act=ACT_NONE, slope=0.0, addend=None, ldadd=None, a_mode=A_ROWS, conv_hw=None, cin=0,
-         o_mode=O_ROWS, out_hw=None, cout=0, groups=1, a_gstride=0, w_gstride=0, o_gstride=0):
+         o_mode=O_ROWS, out_hw=None, cout=0, groups=1, a_gstride=0, w_gstride=0, o_gstride=0, b_gstride=0,
+         w_table=None, bias_table=None):
     """out = act(A . W^T + bias) (+ addend); see struct ldm_gemm_desc."""
     lib = _lib.load()
     d = GemmDesc()
@@ -51,11 +52,14 @@ def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=
     if conv_hw is not None:
         d.H, d.W = conv_hw
     d.Cin = cin
-    nseg = len(weights)
+    nseg = 1 if w_table is not None else len(weights)
     d.nseg = nseg
     d.seg_mode = seg_mode
     d.seg_len = (N if seg_mode == SEG_N else K) // nseg
-    for s in range(nseg):
+    if w_table is not None:
+        d.w_table = _dev(w_table, "w_table", torch.int64)
+        d.bias_table = _opt(bias_table, "bias_table", torch.int64)
+    for s in range(0 if w_table is not None else nseg):
         d.w[s] = _dev(weights[s], "weight")
         if weights2 is not None:
             d.w2[s] = _dev(weights2[s], "weight2")
@@ -77,7 +81,7 @@ def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=
         d.OH, d.OW = out_hw
     d.Cout = cout
     d.groups = groups
-    d.a_gstride, d.w_gstride, d.o_gstride = a_gstride, w_gstride, o_gstride
+    d.a_gstride, d.w_gstride, d.o_gstride, d.b_gstride = a_gstride, w_gstride, o_gstride, b_gstride
     _lib.check(lib.ldm_gemm_f32(ctypes.byref(d), _stream()), "ldm_gemm_f32")
     return out
 

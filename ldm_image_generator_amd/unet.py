@@ -106,22 +106,31 @@ class SwinBlock(nn.Module):
             self._packed = (key, w.detach().permute(0, 2, 3, 1).reshape(c, 9 * w.shape[1]).contiguous())
         return self._packed[1]
 
-    def forward_rows(self, rows, shape, ctx):
-        """unet.py:38-48 on channels-last rows."""
+    def draw(self):
+        """The block's Python-RNG decisions, in the reference's order (unet.py:39, modules.py:35):
+        returns None when stochastic depth skips the block, else the two expert indices."""
         if self.training and random.random() <= self.stochastic_depth:
+            return None
+        return self.ffn.pick()
+
+    def forward_rows(self, rows, shape, ctx, decision=False, film=None):
+        """unet.py:38-48 on channels-last rows.  ``decision``/``film`` may be supplied by UNet.forward,
+        which draws all decisions up front (same RNG order) and batches every block's FiLM MLP."""
+        picks = self.draw() if decision is False else decision
+        if picks is None:
             return rows
         b, h, w = shape
         m, c = rows.shape
-        film = self.encodings.film_rows(ctx.codes(c, h, w))
+        if film is None:
+            film = self.encodings.film_rows(ctx.codes(c, h, w))
         xf = torch.empty_like(rows)
         ops.channelnorm_film(rows, film, ctx.slot, xf, b, h * w, c, self.norm.eps)
-        picks = self.ffn.pick()                                  # modules.py:35, drawn before any branch output is used
         # y = conv(xf) + bias + res
         y = torch.empty_like(rows)
         g = c // 32
         ops.gemm(xf, m, 32, 288, [self._conv_weight()], y, lda=c, ldw=288, biases=[self.conv.bias.detach()],
                  addend=rows, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=32,
-                 groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32)
+                 groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
         if self.attention_flag:
             self.self_attention.forward_rows(xf, shape, addend=y, out=y)
         self.ffn.forward_rows(xf, addend=y, out=y, picks=picks)
@@ -144,9 +153,12 @@ class SwinStack(nn.Module):
             flag_attn = attention if i >= num_blocks - 2 else False       # unet.py:57
             self.blocks.append(SwinBlock(channels, head_dim, window_size, shift, attention=flag_attn))
 
-    def forward_rows(self, rows, shape, ctx):
+    def forward_rows(self, rows, shape, ctx, plan=None):
         for blk in self.blocks:
-            rows = blk.forward_rows(rows, shape, ctx)
+            if plan is None:
+                rows = blk.forward_rows(rows, shape, ctx)
+            else:
+                rows = blk.forward_rows(rows, shape, ctx, *plan[blk])
         return rows
 
     def forward(self, x, t, c=None):
@@ -181,18 +193,62 @@ class UNet(nn.Module):
         self.input_channels = input_channels
         self.channels = list(channels)
         self._uniform_time = None          # set by DDPM.sample: every sample shares this timestep
+        self._tables = {}
+
+    def _level_blocks(self, i):
+        n = len(self.encoder_stages)
+        return list(self.encoder_stages[i].stage.blocks) + list(self.decoder_stages[n - 1 - i].stage.blocks)
+
+    def _pointer_tables(self, i, blocks, dev):
+        """Device arrays of the level's proj1/proj2 weight and bias addresses (rebuilt if any moved)."""
+        ptrs = []
+        for name in ("proj1", "proj2"):
+            ptrs.append([getattr(b.encodings, name).weight.data_ptr() for b in blocks])
+            ptrs.append([getattr(b.encodings, name).bias.data_ptr() for b in blocks])
+        key = (str(dev), tuple(map(tuple, ptrs)))
+        hit = self._tables.get(i)
+        if hit is None or hit[0] != key:
+            hit = (key, [torch.tensor(p, dtype=torch.int64, device=dev) for p in ptrs])
+            self._tables[i] = hit
+        return hit[1]
+
+    def _films(self, ctx, h, w, dev):
+        """FiLM rows (mul | bias) of EVERY SwinBlock, one pair of grouped GEMM launches per level
+        (unet.py:18-21 for all blocks of the level at once; they only depend on t, not on x)."""
+        films = {}
+        for i, c in enumerate(self.channels):
+            blocks = self._level_blocks(i)
+            codes = ctx.codes(c, h >> i, w >> i)
+            m, g = codes.shape[0], len(blocks)
+            w1, b1, w2, b2 = self._pointer_tables(i, blocks, dev)
+            hid = torch.empty(g, m, 4 * c, device=dev, dtype=torch.float32)
+            ops.gemm(codes, m, 4 * c, 2 * c, None, hid, w_table=w1, bias_table=b1, act=ops.ACT_RELU, groups=g,
+                     a_gstride=0, o_gstride=m * 4 * c)
+            film = torch.empty(g, m, 2 * c, device=dev, dtype=torch.float32)
+            ops.gemm(hid, m, 2 * c, 4 * c, None, film, w_table=w2, bias_table=b2, groups=g,
+                     a_gstride=m * 4 * c, o_gstride=m * 2 * c)
+            for k, blk in enumerate(blocks):
+                films[blk] = film[k]
+        return films
 
     def forward(self, x, time, condition=None):
         b, cin, h, w = x.shape
         dev = x.device
         ctx = TimeContext(time, b, dev, uniform=self._uniform_time)
+        # Python-RNG decisions of all 36 blocks in execution order (identical draw order to the
+        # reference, which draws them lazily inside each block: nothing else touches `random`).
+        order = [blk for l in self.encoder_stages for blk in l.stage.blocks] + \
+                [blk for l in self.decoder_stages for blk in l.stage.blocks]
+        decisions = {blk: blk.draw() for blk in order}
+        films = self._films(ctx, h, w, dev)
+        plan = {blk: (decisions[blk], films[blk]) for blk in order}
         c0 = self.channels[0]
         rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
         ops.stem_nchw(x.contiguous().float(), w2d(self.encoder_first), self.encoder_first.bias.detach(), rows, b, cin, h * w, c0)
         skips = []
         n = len(self.encoder_stages)
         for i, l in enumerate(self.encoder_stages):
-            rows = l.stage.forward_rows(rows, (b, h, w), ctx)
+            rows = l.stage.forward_rows(rows, (b, h, w), ctx, plan)
             if i == n - 1:
                 skips.insert(0, None)                                  # unet.py:94-95 (adds the integer 0)
             else:
@@ -217,7 +273,7 @@ class UNet(nn.Module):
                 rows = up
             elif s is not None:
                 raise RuntimeError("unexpected skip at an Identity ch_conv")
-            rows = l.stage.forward_rows(rows, (b, h, w), ctx)
+            rows = l.stage.forward_rows(rows, (b, h, w), ctx, plan)
         out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
         wl = self.decoder_last.weight.detach().reshape(c0, cin)         # ConvTranspose2d weight [C0, Cin, 1, 1]
         ops.head_nchw(rows, wl, self.decoder_last.bias.detach(), out, b, c0, h * w, cin)

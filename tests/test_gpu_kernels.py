@@ -97,7 +97,7 @@ def test_grouped_conv3x3(ops, gpu_device, B, H, W, C):
     wp = w.permute(0, 2, 3, 1).reshape(C, 288).contiguous().cuda()
     out = torch.empty(B * H * W, C, device=gpu_device)
     ops.gemm(rows, B * H * W, 32, 288, [wp], out, lda=C, ldw=288, biases=[b.cuda()], addend=add, ldadd=C, ldo=C,
-             a_mode=ops.A_CONV3X3, conv_hw=(H, W), cin=32, groups=C // 32, a_gstride=32, w_gstride=32 * 288, o_gstride=32)
+             a_mode=ops.A_CONV3X3, conv_hw=(H, W), cin=32, groups=C // 32, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1, groups=C // 32) + res.double()
     got = out.cpu().reshape(B, H, W, C).permute(0, 3, 1, 2)
     assert rel_l2(got, ref) < KTOL
@@ -252,3 +252,25 @@ def test_errors_are_reported_not_thrown(ops, gpu_device):
         ops.gemm(a, 4, 32, 40, [torch.zeros(32, 40, device=gpu_device)], torch.zeros(4, 32, device=gpu_device))   # K % 32
     with pytest.raises(LdmHipUnavailable):
         ops.avgpool2(torch.zeros(1, 4, 4, 8), torch.zeros(1, 2, 2, 8), 1, 4, 4, 8)                                   # CPU tensor
+
+
+def test_gemm_pointer_table_groups(ops, gpu_device):
+    """Independent layers batched on grid.y through device pointer tables (UNet._films)."""
+    G, M, N, K = 5, 48, 128, 64
+    a = rnd(M, K)
+    ws = [rnd(N, K, seed=100 + g, scale=K ** -0.5).cuda() for g in range(G)]
+    bs = [rnd(N, seed=200 + g).cuda() for g in range(G)]
+    wt = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device=gpu_device)
+    bt = torch.tensor([b.data_ptr() for b in bs], dtype=torch.int64, device=gpu_device)
+    hid = torch.empty(G, M, N, device=gpu_device)
+    ops.gemm(a.cuda(), M, N, K, None, hid, w_table=wt, bias_table=bt, act=ops.ACT_RELU, groups=G, a_gstride=0, o_gstride=M * N)
+    for g in range(G):
+        ref = torch.relu(a.double() @ ws[g].cpu().double().t() + bs[g].cpu().double())
+        assert rel_l2(hid[g].cpu(), ref) < KTOL
+    # second layer: per-group A
+    w2 = [rnd(64, N, seed=300 + g, scale=N ** -0.5).cuda() for g in range(G)]
+    wt2 = torch.tensor([w.data_ptr() for w in w2], dtype=torch.int64, device=gpu_device)
+    out = torch.empty(G, M, 64, device=gpu_device)
+    ops.gemm(hid, M, 64, N, None, out, w_table=wt2, groups=G, a_gstride=M * N, o_gstride=M * 64)
+    for g in range(G):
+        assert rel_l2(out[g].cpu(), hid[g].cpu().double() @ w2[g].cpu().double().t()) < KTOL
