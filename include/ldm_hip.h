@@ -31,6 +31,7 @@ extern "C" {
 #define LDM_ENODEV     -3   /* no gfx950 device                                */
 
 #define LDM_MAX_SEG     4
+#define LDM_MAX_TABLE   32
 
 /* epilogue activation of ldm_gemm_f32 */
 #define LDM_ACT_NONE    0
@@ -98,8 +99,10 @@ typedef struct ldm_gemm_desc {
     long long    o_gstride;  /* floats added to out and addend per group          */
     long long    b_gstride;  /* floats added to every bias pointer per group      */
     /* pointer-table mode (independent layers batched into one launch, e.g. the
-     * Encodings MLPs of all SwinBlocks of one UNet level): DEVICE arrays of
-     * `groups` pointers that replace w[0] / bias[0] for group g (nseg must be 1). */
+     * Encodings MLPs of all SwinBlocks of one UNet level): HOST arrays of `groups`
+     * (<= LDM_MAX_TABLE) DEVICE pointers that replace w[0] / bias[0] for group g
+     * (nseg must be 1).  They are copied into the kernel arguments, so the kernel
+     * reads them with scalar loads and no device-side table has to exist. */
     const float *const *w_table;
     const float *const *bias_table;
 } ldm_gemm_desc;
@@ -109,6 +112,9 @@ const char *ldm_last_error(void);
 int         ldm_device_ok(void);          /* 1 if device 0 is gfx950 */
 
 int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
+/* schedule used by ldm_gemm_f32: 0 = one tile per workgroup, 1 = persistent LDS-DMA stream (default).
+ * Both give bit-identical results; returns the previous setting (any other v only queries). */
+int ldm_gemm_variant(int v);
 
 /* hot-kernel timing for bench.py: when enabled every ldm_gemm_f32 launch is
  * bracketed by hipEvents on ITS stream; ldm_prof_read synchronises those events

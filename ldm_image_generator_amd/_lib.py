@@ -55,6 +55,7 @@ SIGNATURES = {
     "ldm_last_error": (ctypes.c_char_p, []),
     "ldm_device_ok": (_I, []),
     "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
+    "ldm_gemm_variant": (_I, [_I]),
     "ldm_prof_enable": (_I, [_I]),
     "ldm_prof_read": (_I, [ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ldm_channelnorm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),

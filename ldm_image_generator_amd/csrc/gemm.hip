@@ -19,36 +19,14 @@
 // im2col).  Runtime: weight segments selected by pointer (RandomMoE experts are
 // never copied), bias/activation/addend, output scatter (rows | ConvTranspose
 // 2x2 | nearest-x2 replicate), groups on grid.y.
-#include "common.h"
+#include "gemm_common.h"
+#include <cstdlib>
 #include <vector>
 #include <mutex>
 
+using namespace ldmgemm;
+
 namespace {
-
-struct GemmP {
-    const float *a;
-    long long lda;
-    int M, N, K;
-    int H, W, Cin, cpt;          // conv: chunks (of 32 channels) per tap
-    int nseg, seg_mode, seg_len;
-    const float *w[LDM_MAX_SEG];
-    const float *w2[LDM_MAX_SEG];
-    const float *bias[LDM_MAX_SEG];
-    const float *bias2[LDM_MAX_SEG];
-    long long ldw;
-    int act;
-    float slope;
-    const float *addend;
-    long long ldadd;
-    float *out;
-    long long ldo;
-    int o_mode, OH, OW, Cout;
-    long long a_gstride, w_gstride, o_gstride, b_gstride;
-    const float *const *w_table;
-    const float *const *bias_table;
-};
-
-__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
@@ -114,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
             seg = (kt << 5) / p.seg_len;
             kcol -= (long long)seg * p.seg_len;
         }
-        const float *wa = (p.w_table ? p.w_table[g] : p.w[seg] + g * p.w_gstride) + kcol + chunk * 4;
+        const float *wa = (p.use_table ? p.wtab[g] : p.w[seg] + g * p.w_gstride) + kcol + chunk * 4;
         const float *wb = GATE ? p.w2[seg] + g * p.w_gstride + kcol + chunk * 4 : nullptr;
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
@@ -175,83 +153,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
         __syncthreads();
     }
 
-    // ---- epilogue ----------------------------------------------------------
-    const long long gcol = g * p.o_gstride;
-    const long long gb = g * p.b_gstride;
-    const float *tbias = p.bias_table ? p.bias_table[g] : nullptr;
-    float b1[TN], b2[TN];
-    int q4[TN];
-    long long ocol[TN];
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int nloc = n0 + (wn * TN + jn) * 32 + r;      // column inside this group's N
-        int bidx = (p.seg_mode == LDM_SEG_N) ? nloc - seg_n * p.seg_len : nloc;
-        int co = nloc;
-        q4[jn] = 0;
-        if (p.o_mode == LDM_O_CONVT2X2) {
-            q4[jn] = nloc / p.Cout;
-            co = nloc - q4[jn] * p.Cout;
-            bidx = co;
-        }
-        ocol[jn] = gcol + co;
-        b1[jn] = 0.f;
-        b2[jn] = 0.f;
-        if (tbias) {
-            b1[jn] = tbias[bidx];
-        } else if (p.seg_mode == LDM_SEG_K) {
-            if (p.bias[0]) b1[jn] += p.bias[0][gb + bidx];
-            if (p.nseg > 1 && p.bias[1]) b1[jn] += p.bias[1][gb + bidx];
-            if (p.nseg > 2 && p.bias[2]) b1[jn] += p.bias[2][gb + bidx];
-            if (p.nseg > 3 && p.bias[3]) b1[jn] += p.bias[3][gb + bidx];
-        } else {
-            if (p.bias[seg_n]) b1[jn] = p.bias[seg_n][gb + bidx];
-            if (GATE && p.bias2[seg_n]) b2[jn] = p.bias2[seg_n][gb + bidx];
-        }
-    }
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const bool live = m < p.M;
-            long long orow0 = m;
-            int ox2 = 0;
-            if (p.o_mode != LDM_O_ROWS) {
-                const int xx = m % p.OW;
-                const int yy = (m / p.OW) % p.OH;
-                const long long bb = m / (p.OW * p.OH);
-                ox2 = 2 * p.OW;
-                orow0 = (bb * 2 * p.OH + 2 * yy) * ox2 + 2 * xx;        // top-left fine pixel
-            }
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                float v = acc[0][im][jn][e] + b1[jn];
-                if (GATE) {
-                    const float gt = acc[NACC - 1][im][jn][e] + b2[jn];
-                    v = v * fmaxf(gt, 0.f);
-                } else if (p.act == LDM_ACT_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (p.act == LDM_ACT_LRELU) {
-                    v = v > 0.f ? v : v * p.slope;
-                }
-                if (live) {
-                    if (p.o_mode == LDM_O_UP2) {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const long long orow = orow0 + (d >> 1) * ox2 + (d & 1);
-                            float o = v;
-                            if (p.addend) o += p.addend[orow * p.ldadd + ocol[jn]];
-                            p.out[orow * p.ldo + ocol[jn]] = o;
-                        }
-                    } else {
-                        const long long orow = orow0 + (q4[jn] >> 1) * ox2 + (q4[jn] & 1);
-                        if (p.addend) v += p.addend[orow * p.ldadd + ocol[jn]];
-                        p.out[orow * p.ldo + ocol[jn]] = v;
-                    }
-                }
-            }
-        }
-    }
+    float no_pre[TM][TN][16];
+    EpiCols<TN> cols;
+    gemm_epilogue_cols<WN, TN, GATE>(p, cols, n0, g, seg_n, wn, r);
+    gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, m0, wm, h, cols, no_pre, false);
 }
 
 // ---------------------------------------------------------------------------
@@ -293,12 +198,25 @@ int dispatch(const GemmP &p, int groups, hipStream_t st)
         return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch<1, 4, 1, 1, GATE, AMODE>(p, groups, st);
+    static const char *force = getenv("LDM_GEMM_TILE");          // experiment knob: "128x64"
+    if (force && force[4] == '6' && unit % 64 == 0) return launch<2, 2, 2, 1, GATE, AMODE>(p, groups, st);
     if (unit % 128 == 0) return launch<2, 2, 2, 2, GATE, AMODE>(p, groups, st);
     if (unit % 64 == 0) return launch<2, 2, 2, 1, GATE, AMODE>(p, groups, st);
     return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);
 }
 
+int g_variant = 1;      // 0: tile-per-block kernel, 1: persistent LDS-DMA stream kernel
+
 }  // namespace
+
+int ldm_gemm_stream_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st);
+
+extern "C" int ldm_gemm_variant(int v)
+{
+    const int old = g_variant;
+    if (v == 0 || v == 1) g_variant = v;
+    return old;
+}
 
 extern "C" int ldm_prof_enable(int on)
 {
@@ -377,7 +295,15 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
         if (d->o_mode == LDM_O_CONVT2X2) LDM_REQUIRE(d->Cout > 0 && d->N == 4 * d->Cout, "ldm_gemm_f32: convT2x2 needs N == 4*Cout");
     }
     p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.o_gstride = d->o_gstride; p.b_gstride = d->b_gstride;
-    p.w_table = d->w_table; p.bias_table = d->bias_table;
+    p.use_table = d->w_table ? 1 : 0;
+    if (d->w_table) {
+        LDM_REQUIRE(groups <= LDM_MAX_TABLE, "ldm_gemm_f32: pointer-table mode supports at most %d groups", LDM_MAX_TABLE);
+        for (int i = 0; i < groups; ++i) {
+            LDM_REQUIRE(d->w_table[i] && ldm_aligned16(d->w_table[i]), "ldm_gemm_f32: table weight %d null/unaligned", i);
+            p.wtab[i] = d->w_table[i];
+            p.btab[i] = d->bias_table ? d->bias_table[i] : nullptr;
+        }
+    }
 
     hipStream_t st = (hipStream_t)stream;
     ProfRec *rec = nullptr;
@@ -397,8 +323,10 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
             (void)hipEventRecord(rec->start, st);
         }
     }
-    if (gate) {
-        if (d->a_mode == LDM_A_CONV3X3) { ldm_set_error("ldm_gemm_f32: GATE with conv3x3 unsupported"); return LDM_EINVAL; }
+    if (gate && d->a_mode == LDM_A_CONV3X3) { ldm_set_error("ldm_gemm_f32: GATE with conv3x3 unsupported"); return LDM_EINVAL; }
+    if (g_variant == 1 && ldm_gemm_stream_dispatch(p, groups, gate, d->a_mode, st)) {
+        // launched on the stream kernel
+    } else if (gate) {
         dispatch<true, LDM_A_ROWS>(p, groups, st);
     } else if (d->a_mode == LDM_A_CONV3X3) {
         dispatch<false, LDM_A_CONV3X3>(p, groups, st);

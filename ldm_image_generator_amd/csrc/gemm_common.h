@@ -1,0 +1,148 @@
+// Shared pieces of the two fp32-MFMA GEMM kernels (tile-per-block `gemm_f32_kernel`
+// and the persistent LDS-DMA stream `gemm_stream_kernel`).
+#pragma once
+#include "common.h"
+
+namespace ldmgemm {
+
+struct GemmP {
+    const float *a;
+    long long lda;
+    int M, N, K;
+    int H, W, Cin, cpt;          // conv: chunks (of 32 channels) per tap
+    int nseg, seg_mode, seg_len;
+    const float *w[LDM_MAX_SEG];
+    const float *w2[LDM_MAX_SEG];
+    const float *bias[LDM_MAX_SEG];
+    const float *bias2[LDM_MAX_SEG];
+    long long ldw;
+    int act;
+    float slope;
+    const float *addend;
+    long long ldadd;
+    float *out;
+    long long ldo;
+    int o_mode, OH, OW, Cout;
+    long long a_gstride, w_gstride, o_gstride, b_gstride;
+    int use_table;                              // pointer-table mode: per-group weights / biases below
+    const float *wtab[LDM_MAX_TABLE];
+    const float *btab[LDM_MAX_TABLE];
+};
+
+// 64 B of zeros (one copy per translation unit): target of "absent operand" loads, so that optional
+// biases and conv zero-padding need no branch around a load
+static __device__ __attribute__((aligned(64))) float ldm_zero_block[16];
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+
+// Epilogue of one BM x BN tile: bias, activation / gate, optional addend, rows | convT 2x2 | up2 addressing.
+// acc layout (32x32 MFMA C/D map): column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+// `pre` holds addend values prefetched by the caller (o_mode == ROWS) when use_pre is set.
+template <int TN>
+struct EpiCols {
+    float braw[LDM_MAX_SEG][TN];     // loaded, not yet summed: no arithmetic (hence no wait) at the load site
+    float b2[TN];
+    int q4[TN];
+    long long ocol[TN];
+};
+
+// Column-side epilogue state (bias values, output columns): plain global loads, so the stream kernel
+// issues them together with the addend prefetch, ahead of the tile's last K-step.
+template <int WN, int TN, bool GATE>
+__device__ __forceinline__ void gemm_epilogue_cols(const GemmP &p, EpiCols<TN> &c, int n0, int g, int seg_n, int wn, int r)
+{
+    const long long gcol = g * p.o_gstride;
+    const long long gb = g * p.b_gstride;
+    const float *tbias = p.use_table ? p.btab[g] : nullptr;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int nloc = n0 + (wn * TN + jn) * 32 + r;      // column inside this group's N
+        int bidx = (p.seg_mode == LDM_SEG_N) ? nloc - seg_n * p.seg_len : nloc;
+        int co = nloc;
+        c.q4[jn] = 0;
+        if (p.o_mode == LDM_O_CONVT2X2) {
+            c.q4[jn] = nloc / p.Cout;
+            co = nloc - c.q4[jn] * p.Cout;
+            bidx = co;
+        }
+        c.ocol[jn] = gcol + co;
+        // unconditional loads through SELECTED pointers (absent bias -> zero block): one straight-line
+        // path with no branch, so all loads issue back to back and are waited for once, at their first
+        // use after the MFMAs (a branch here makes hipcc drain the LDS-DMA queue with vmcnt(0))
+        const bool ksum = p.seg_mode == LDM_SEG_K && !p.use_table;
+        const float *first = p.use_table ? tbias : p.bias[seg_n];
+        const long long off0 = (p.use_table ? 0 : gb) + bidx;
+#pragma unroll
+        for (int sgi = 0; sgi < LDM_MAX_SEG; ++sgi) {
+            const float *base = ksum ? p.bias[sgi] : (sgi == 0 ? first : nullptr);
+            const float *bp = base ? base + (ksum ? gb + bidx : off0) : ldm_zero_block;
+            c.braw[sgi][jn] = *bp;
+        }
+        if (GATE) {
+            const float *bq = p.bias2[seg_n] ? p.bias2[seg_n] + gb + bidx : ldm_zero_block;
+            c.b2[jn] = *bq;
+        } else {
+            c.b2[jn] = 0.f;
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool GATE>
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int wm, int h,
+                                              const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre)
+{
+    constexpr int NACC = GATE ? 2 : 1;
+    float b1[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) b1[jn] = ((c.braw[0][jn] + c.braw[1][jn]) + c.braw[2][jn]) + c.braw[3][jn];
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const bool live = m < p.M;
+            long long orow0 = m;
+            int ox2 = 0;
+            if (p.o_mode != LDM_O_ROWS) {
+                const int xx = m % p.OW;
+                const int yy = (m / p.OW) % p.OH;
+                const long long bb = m / (p.OW * p.OH);
+                ox2 = 2 * p.OW;
+                orow0 = (bb * 2 * p.OH + 2 * yy) * ox2 + 2 * xx;        // top-left fine pixel
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                float v = acc[0][im][jn][e] + b1[jn];
+                if (GATE) {
+                    const float gt = acc[NACC - 1][im][jn][e] + c.b2[jn];
+                    v = v * fmaxf(gt, 0.f);
+                } else if (p.act == LDM_ACT_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (p.act == LDM_ACT_LRELU) {
+                    v = v > 0.f ? v : v * p.slope;
+                }
+                // prefetched addend: consumed on every path (also for clamped, non-stored rows) so that the
+                // compiler retires those loads here and never drains the LDS-DMA queue elsewhere for them
+                if (use_pre) v += pre[im][jn][e];
+                if (live) {
+                    if (p.o_mode == LDM_O_UP2) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const long long orow = orow0 + (d >> 1) * ox2 + (d & 1);
+                            float o = v;
+                            if (p.addend) o += p.addend[orow * p.ldadd + c.ocol[jn]];
+                            p.out[orow * p.ldo + c.ocol[jn]] = o;
+                        }
+                    } else {
+                        const long long orow = orow0 + (c.q4[jn] >> 1) * ox2 + (c.q4[jn] & 1);
+                        if (!use_pre && p.addend) v += p.addend[orow * p.ldadd + c.ocol[jn]];
+                        p.out[orow * p.ldo + c.ocol[jn]] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ldmgemm

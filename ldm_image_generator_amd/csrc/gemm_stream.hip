@@ -1,0 +1,291 @@
+// Persistent, LDS-DMA-fed fp32-MFMA GEMM ("stream" kernel).
+//
+// Same math and operand conventions as gemm_f32_kernel (gemm.hip), different schedule:
+//   * resident workgroups (2 per CU) walk a static, XCD-aware list of output tiles; the K-steps of ALL
+//     tiles of a workgroup form one continuous stream, so a tile's first K-step and its epilogue never
+//     expose memory latency (short-K shapes such as C = 128 otherwise live in exactly those two places);
+//   * operands go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write pass) into
+//     a 2-stage ring; the DMA for step s+1 is issued at the top of step s;
+//   * ONE sync point per K-step, placed before the LAST quarter of the step's MFMAs: the fragments of that
+//     quarter are already in registers, so after the barrier a wave still owns 16 MFMAs (1024 cycles) of
+//     work under which it fetches the next step's first fragments -- the matrix pipe never drains at a
+//     step boundary;
+//   * bias / addend values of a tile are prefetched (branch-free) under its last K-step.
+// LDS-DMA writes lane-linear (wave-uniform base + lane*16 B), so the 16-B-chunk XOR swizzle is applied to
+// the per-lane SOURCE address; fragment reads use the same swizzle.  Rows past M are clamped (their results
+// are never stored); zero padding of the implicit 3x3 im2col reads a 64-B block of zeros.
+#include "gemm_common.h"
+#include <cstdlib>
+
+using namespace ldmgemm;
+
+namespace {
+
+constexpr int NS = 2;      // LDS ring stages
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void glds16(const float *src, float *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NB = GATE ? 2 * BN : BN;
+    constexpr int A_F4 = BM / 32, B_F4 = NB / 32;
+    constexpr int STAGE = (BM + NB) * 32;
+    constexpr int NACC = GATE ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int chunk = t & 7, lrow = t >> 3;
+    const int nk = p.K >> 5;
+    const int per_group = ntm * ntn;
+
+    // tiles of this workgroup: logical ids xcd_remap(blockIdx.x + i * gridDim.x)
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_steps = my_tiles * nk;
+
+    auto tile_coords = [&](int i, int &g, int &m0, int &n0) {
+        const int id = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, total_tiles);
+        g = id / per_group;
+        const int rem = id - g * per_group;
+        const int tm_ = rem / ntn;
+        m0 = tm_ * BM;
+        n0 = (rem - tm_ * ntn) * BN;
+    };
+
+    // ---- loader cursor -------------------------------------------------------
+    int l_tile = 0, l_kt = 0, l_step = 0, l_g = 0, l_seg_n = 0;
+    const float *a_ptr[A_F4];
+    int a_y[A_F4], a_x[A_F4];
+    long long b_off[B_F4];
+
+    auto loader_setup = [&]() {
+        int m0, n0;
+        tile_coords(l_tile, l_g, m0, n0);
+        l_seg_n = (p.seg_mode == LDM_SEG_N) ? n0 / p.seg_len : 0;
+        const int nloc0 = (p.seg_mode == LDM_SEG_N) ? n0 - l_seg_n * p.seg_len : n0;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = lrow + 32 * i;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            const int lchunk = chunk ^ ((row >> 1) & 7);
+            a_ptr[i] = p.a + l_g * p.a_gstride + (long long)m * p.lda + lchunk * 4;
+            if (AMODE == LDM_A_CONV3X3) {
+                a_x[i] = m % p.W;
+                a_y[i] = (m / p.W) % p.H;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int row = lrow + 32 * i;
+            const int nrow = (GATE && row >= BN) ? row - BN : row;
+            const int lchunk = chunk ^ ((row >> 1) & 7);
+            b_off[i] = (long long)(nloc0 + nrow) * p.ldw + lchunk * 4;
+        }
+    };
+
+    auto loader_issue = [&]() {
+        float *As = lds + (l_step & 1) * STAGE, *Bs = As + BM * 32;
+        const int kt = l_kt;
+        if (AMODE == LDM_A_CONV3X3) {
+            const int tap = kt / p.cpt;
+            const int c0 = (kt - tap * p.cpt) << 5;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long long shift = (long long)(dy * p.W + dx) * p.lda + c0;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
+                glds16(ok ? a_ptr[i] + shift : ldm_zero_block + (chunk & 3) * 4, As + (i * 4 + wave) * 256);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) glds16(a_ptr[i] + ((long long)kt << 5), As + (i * 4 + wave) * 256);
+        }
+        int seg = l_seg_n;
+        long long kcol = (long long)kt << 5;
+        if (p.seg_mode == LDM_SEG_K) {
+            seg = (kt << 5) / p.seg_len;
+            kcol -= (long long)seg * p.seg_len;
+        }
+        const float *wa = (p.use_table ? p.wtab[l_g] : p.w[seg] + l_g * p.w_gstride) + kcol;
+        const float *wb = GATE ? p.w2[seg] + l_g * p.w_gstride + kcol : nullptr;
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const bool second = GATE && (32 * i >= BN);
+            glds16((second ? wb : wa) + b_off[i], Bs + (i * 4 + wave) * 256);
+        }
+        ++l_step;
+        if (++l_kt == nk) {
+            l_kt = 0;
+            ++l_tile;
+            if (l_tile < my_tiles) loader_setup();
+        }
+    };
+
+    // ---- consumer ------------------------------------------------------------
+    f32x16 acc[NACC][TM][TN];
+    float pre[TM][TN][16];
+    f32x4 fa0[TM], fb0[NACC][TN], fa1[TM], fb1[NACC][TN];        // two fragment sets (ping-pong over j)
+    int c_tile = 0, c_kt = 0, c_g = 0, c_m0 = 0, c_n0 = 0;
+    if (my_tiles == 0) return;
+    tile_coords(0, c_g, c_m0, c_n0);
+
+    auto read_frags = [&](int step, int j, f32x4 (&af)[TM], f32x4 (&bf)[NACC][TN]) {
+        const float *As = lds + (step & 1) * STAGE, *Bs = As + BM * 32;
+        const int c = 2 * j + h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const f32x4 *)(As + swz((wm * TM + i) * 32 + r, c));
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bf[q][i] = *(const f32x4 *)(Bs + swz(q * BN + (wn * TN + i) * 32 + r, c));
+    };
+    auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[NACC][TN]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[q][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[q][jj][e], acc[q][i][jj], 0, 0, 0);
+    };
+    // steps 0..2 of the K-step: three quarters of the MFMAs, all remaining fragment reads of this stage
+    auto quarters_0_to_2 = [&](int s) {
+        read_frags(s, 1, fa1, fb1);
+        mma(fa0, fb0);
+        read_frags(s, 2, fa0, fb0);
+        mma(fa1, fb1);
+        read_frags(s, 3, fa1, fb1);
+        mma(fa0, fb0);
+    };
+    // the sync point: this wave's DMA for step s+1 has landed and its reads of stage s are complete;
+    // after the barrier that holds for every wave, so stage s may be overwritten and stage s+1 read
+    auto sync_point = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: stage 0 <- step 0 -------------------------------------------
+    loader_setup();
+    loader_issue();
+    sync_point();
+    read_frags(0, 0, fa0, fb0);
+
+#pragma unroll 1
+    for (int s = 0; s < total_steps; ++s) {
+        const bool more = s + 1 < total_steps;
+        if (more) loader_issue();                         // step s+1 -> stage (s+1)&1 (free since the last barrier)
+        if (c_kt == 0) {
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
+        }
+        if (c_kt != nk - 1) {
+            quarters_0_to_2(s);
+            sync_point();
+            if (more) read_frags(s + 1, 0, fa0, fb0);
+            mma(fa1, fb1);
+            ++c_kt;
+        } else {
+            // last K-step of the tile: bias/addend prefetch, MFMAs and epilogue on ONE control path, so the
+            // only wait for the prefetched registers sits in front of their first use
+            const bool use_pre = p.addend != nullptr && p.o_mode == LDM_O_ROWS;
+            const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
+            EpiCols<TN> cols;
+            gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
+            if (use_pre) {
+                const long long gcol = c_g * p.o_gstride;
+#pragma unroll
+                for (int im = 0; im < TM; ++im)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            int m = c_m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            m = m < p.M ? m : p.M - 1;
+                            pre[im][jn][e] = p.addend[(long long)m * p.ldadd + gcol + c_n0 + (wn * TN + jn) * 32 + r];
+                        }
+            }
+            quarters_0_to_2(s);
+            sync_point();
+            if (more) read_frags(s + 1, 0, fa0, fb0);
+            mma(fa1, fb1);
+            gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
+            c_kt = 0;
+            ++c_tile;
+            if (c_tile < my_tiles) tile_coords(c_tile, c_g, c_m0, c_n0);
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
+int launch_stream(const GemmP &p, int groups, hipStream_t st)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NB = GATE ? 2 * BN : BN;
+    constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
+    static int slots = 0;
+    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE>;
+    if (slots == 0) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
+        slots = cus * (per_cu > 4 ? 4 : per_cu);                          // resident workgroups (no grid barrier: a wrong guess only skews load)
+    }
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    const long long total = (long long)ntm * ntn * groups;
+    if (total > 0x7fffffffLL) return 0;
+    int grid = (int)(total < slots ? total : slots);
+    if (grid > 8) grid &= ~7;                                          // keep blockIdx % 8 == XCD label across rounds
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p, ntm, ntn, (int)total);
+    return 1;
+}
+
+}  // namespace
+
+// Chooses a stream-kernel instance for the problem; returns 1 if it launched, 0 if the caller should
+// fall back to the tile-per-block kernel.
+int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, hipStream_t st)
+{
+    const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
+    if (gate) {
+        if (amode != LDM_A_ROWS) return 0;
+        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS>(p, groups, st);
+        return launch_stream<4, 1, 1, 1, true, LDM_A_ROWS>(p, groups, st);
+    }
+    // 128x64 output tiles (not 128x128): 96 fewer live registers in the last-step path (no spills at two
+    // workgroups per CU), twice the tiles (finer wave quantisation at the deep stages)
+    if (amode == LDM_A_CONV3X3) {
+        // measured (tools/gemm_bench.py): the implicit-im2col shapes (long K, per-step tap predicates) run
+        // 8-15 % faster on the tile-per-workgroup kernel; LDM_GEMM_STREAM_CONV=1 forces the stream kernel
+        static const bool force_conv = getenv("LDM_GEMM_STREAM_CONV") != nullptr;
+        if (!force_conv) return 0;
+        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_CONV3X3>(p, groups, st);
+        return launch_stream<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
+    }
+    if (p.M <= 32 && unit % 128 == 0) return launch_stream<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+    if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
+    return launch_stream<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+}

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O_CONVT2X2, O_ROWS, O_UP2, SEG_K, SEG_N,
                    GemmDesc)
 
-__all__ = ["gemm", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
+__all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
            "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
@@ -56,9 +56,9 @@ def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=
     d.nseg = nseg
     d.seg_mode = seg_mode
     d.seg_len = (N if seg_mode == SEG_N else K) // nseg
-    if w_table is not None:
-        d.w_table = _dev(w_table, "w_table", torch.int64)
-        d.bias_table = _opt(bias_table, "bias_table", torch.int64)
+    if w_table is not None:                 # host ctypes arrays of device addresses (see pointer_table)
+        d.w_table = ctypes.cast(w_table, ctypes.c_void_p)
+        d.bias_table = None if bias_table is None else ctypes.cast(bias_table, ctypes.c_void_p)
     for s in range(0 if w_table is not None else nseg):
         d.w[s] = _dev(weights[s], "weight")
         if weights2 is not None:
@@ -84,6 +84,14 @@ def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=
     d.a_gstride, d.w_gstride, d.o_gstride, d.b_gstride = a_gstride, w_gstride, o_gstride, b_gstride
     _lib.check(lib.ldm_gemm_f32(ctypes.byref(d), _stream()), "ldm_gemm_f32")
     return out
+
+
+def pointer_table(tensors):
+    """Host array of device addresses for gemm(w_table=/bias_table=); keep it alive during the call."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = _dev(t, "table entry")
+    return arr
 
 
 def channelnorm_film(x, film, slot, out, B, HW, C, eps=1e-4):
@@ -172,6 +180,11 @@ def to_uint8_hwc(img, out, B, C, HW):
     lib = _lib.load()
     _lib.check(lib.ldm_to_uint8_hwc(_dev(img, "img"), _dev(out, "out", torch.uint8), B, C, HW, _stream()), "ldm_to_uint8_hwc")
     return out
+
+
+def gemm_variant(v):
+    """0 = tile-per-block schedule, 1 = persistent LDS-DMA stream; returns the previous value."""
+    return _lib.load().ldm_gemm_variant(v)
 
 
 def prof_enable(on):

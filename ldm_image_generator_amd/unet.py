@@ -200,15 +200,15 @@ class UNet(nn.Module):
         return list(self.encoder_stages[i].stage.blocks) + list(self.decoder_stages[n - 1 - i].stage.blocks)
 
     def _pointer_tables(self, i, blocks, dev):
-        """Device arrays of the level's proj1/proj2 weight and bias addresses (rebuilt if any moved)."""
-        ptrs = []
+        """Host arrays of the level's proj1/proj2 weight and bias addresses (rebuilt if any moved)."""
+        tens = []
         for name in ("proj1", "proj2"):
-            ptrs.append([getattr(b.encodings, name).weight.data_ptr() for b in blocks])
-            ptrs.append([getattr(b.encodings, name).bias.data_ptr() for b in blocks])
-        key = (str(dev), tuple(map(tuple, ptrs)))
+            tens.append([getattr(b.encodings, name).weight.detach() for b in blocks])
+            tens.append([getattr(b.encodings, name).bias.detach() for b in blocks])
+        key = (str(dev), tuple(t.data_ptr() for ts in tens for t in ts))
         hit = self._tables.get(i)
         if hit is None or hit[0] != key:
-            hit = (key, [torch.tensor(p, dtype=torch.int64, device=dev) for p in ptrs])
+            hit = (key, [ops.pointer_table(ts) for ts in tens])
             self._tables[i] = hit
         return hit[1]
 

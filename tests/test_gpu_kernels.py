@@ -17,12 +17,15 @@ pytestmark = pytest.mark.gpu
 KTOL = 1e-5
 
 
-@pytest.fixture(scope="module")
-def ops(gpu_device):
+@pytest.fixture(scope="module", params=["stream", "tile"])
+def ops(gpu_device, request):
+    """Every kernel test runs under both GEMM schedules (persistent LDS-DMA stream / one tile per workgroup)."""
     from ldm_image_generator_amd import ops as _ops
     from ldm_image_generator_amd import _lib
     assert _lib.load().ldm_device_ok() == 1, "device 0 is not gfx950"
-    return _ops
+    old = _ops.gemm_variant(1 if request.param == "stream" else 0)
+    yield _ops
+    _ops.gemm_variant(old)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -260,8 +263,7 @@ def test_gemm_pointer_table_groups(ops, gpu_device):
     a = rnd(M, K)
     ws = [rnd(N, K, seed=100 + g, scale=K ** -0.5).cuda() for g in range(G)]
     bs = [rnd(N, seed=200 + g).cuda() for g in range(G)]
-    wt = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device=gpu_device)
-    bt = torch.tensor([b.data_ptr() for b in bs], dtype=torch.int64, device=gpu_device)
+    wt, bt = ops.pointer_table(ws), ops.pointer_table(bs)
     hid = torch.empty(G, M, N, device=gpu_device)
     ops.gemm(a.cuda(), M, N, K, None, hid, w_table=wt, bias_table=bt, act=ops.ACT_RELU, groups=G, a_gstride=0, o_gstride=M * N)
     for g in range(G):
@@ -269,8 +271,27 @@ def test_gemm_pointer_table_groups(ops, gpu_device):
         assert rel_l2(hid[g].cpu(), ref) < KTOL
     # second layer: per-group A
     w2 = [rnd(64, N, seed=300 + g, scale=N ** -0.5).cuda() for g in range(G)]
-    wt2 = torch.tensor([w.data_ptr() for w in w2], dtype=torch.int64, device=gpu_device)
+    wt2 = ops.pointer_table(w2)
     out = torch.empty(G, M, 64, device=gpu_device)
     ops.gemm(hid, M, 64, N, None, out, w_table=wt2, groups=G, a_gstride=M * N, o_gstride=M * 64)
     for g in range(G):
         assert rel_l2(out[g].cpu(), hid[g].cpu().double() @ w2[g].cpu().double().t()) < KTOL
+
+
+def test_gemm_schedules_bit_identical(gpu_device):
+    """The stream and tile-per-workgroup schedules run the same fmaf chains: outputs must match bitwise,
+    including many-tiles-per-workgroup problems (persistent loop, ragged M, short K)."""
+    from ldm_image_generator_amd import ops as o
+    for (M, N, K) in [(70000, 128, 128), (33000, 384, 32), (4100, 1024, 64), (257, 2048, 96)]:
+        a, w, b = rnd(M, K).cuda(), rnd(N, K, seed=1, scale=K ** -0.5).cuda(), rnd(N, seed=2).cuda()
+        add = rnd(M, N, seed=3).cuda()
+        outs = []
+        for v in (0, 1):
+            old = o.gemm_variant(v)
+            out = torch.empty(M, N, device=gpu_device)
+            o.gemm(a, M, N, K, [w], out, biases=[b], addend=add)
+            outs.append(out)
+            o.gemm_variant(old)
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        ref = a.double() @ w.double().t() + b.double() + add.double()
+        assert rel_l2(outs[1].double(), ref) < KTOL
