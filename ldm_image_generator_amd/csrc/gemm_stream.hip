@@ -64,23 +64,39 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     };
 
     // ---- loader cursor -------------------------------------------------------
-    int l_tile = 0, l_kt = 0, l_step = 0, l_g = 0, l_seg_n = 0;
-    const float *a_ptr[A_F4];
+    // Wave-uniform running base pointers (SGPRs) + constant per-lane 32-bit offsets: advancing the stream
+    // by one K-step is a handful of scalar adds, no per-lane 64-bit address arithmetic and no division.
+    int l_tile = 0, l_kt = 0, l_step = 0, l_g = 0;
+    int l_seg = 0, l_kin = 0;                    // weight segment of the current K-step, K-steps done inside it
+    int l_tap = 0, l_cin = 0;                    // conv: tap index, 32-channel chunk inside the tap
+    const float *a_cur = nullptr;                // A tile base (+ K offset of the current step)
+    const float *w_row0 = nullptr, *w2_row0 = nullptr;   // weight rows of this tile at K offset 0 of the segment
+    int a_voff[A_F4], b_voff[B_F4];              // per-lane element offsets (row * stride + swizzled chunk)
     int a_y[A_F4], a_x[A_F4];
-    long long b_off[B_F4];
+    const int seg_steps = p.seg_mode == LDM_SEG_K ? p.seg_len >> 5 : 0x7fffffff;   // K-steps per weight segment
+    int l_nloc0 = 0;
 
+    auto weight_rows = [&]() {
+        const long long off = (long long)l_nloc0 * p.ldw;
+        w_row0 = (p.use_table ? p.wtab[l_g] : p.w[l_seg] + l_g * p.w_gstride) + off;
+        if (GATE) w2_row0 = p.w2[l_seg] + l_g * p.w_gstride + off;
+    };
     auto loader_setup = [&]() {
         int m0, n0;
         tile_coords(l_tile, l_g, m0, n0);
-        l_seg_n = (p.seg_mode == LDM_SEG_N) ? n0 / p.seg_len : 0;
-        const int nloc0 = (p.seg_mode == LDM_SEG_N) ? n0 - l_seg_n * p.seg_len : n0;
+        l_seg = (p.seg_mode == LDM_SEG_N) ? n0 / p.seg_len : 0;
+        l_nloc0 = (p.seg_mode == LDM_SEG_N) ? n0 - l_seg * p.seg_len : n0;
+        l_kin = 0;
+        l_tap = 0;
+        l_cin = 0;
+        a_cur = p.a + l_g * p.a_gstride + (long long)m0 * p.lda;
+        weight_rows();
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int row = lrow + 32 * i;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
-            const int lchunk = chunk ^ ((row >> 1) & 7);
-            a_ptr[i] = p.a + l_g * p.a_gstride + (long long)m * p.lda + lchunk * 4;
+            a_voff[i] = (m - m0) * (int)p.lda + (chunk ^ ((row >> 1) & 7)) * 4;
             if (AMODE == LDM_A_CONV3X3) {
                 a_x[i] = m % p.W;
                 a_y[i] = (m / p.W) % p.H;
@@ -90,46 +106,45 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         for (int i = 0; i < B_F4; ++i) {
             const int row = lrow + 32 * i;
             const int nrow = (GATE && row >= BN) ? row - BN : row;
-            const int lchunk = chunk ^ ((row >> 1) & 7);
-            b_off[i] = (long long)(nloc0 + nrow) * p.ldw + lchunk * 4;
+            b_voff[i] = nrow * (int)p.ldw + (chunk ^ ((row >> 1) & 7)) * 4;
         }
     };
 
     auto loader_issue = [&]() {
         float *As = lds + (l_step & 1) * STAGE, *Bs = As + BM * 32;
-        const int kt = l_kt;
         if (AMODE == LDM_A_CONV3X3) {
-            const int tap = kt / p.cpt;
-            const int c0 = (kt - tap * p.cpt) << 5;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const long long shift = (long long)(dy * p.W + dx) * p.lda + c0;
+            const int dy = l_tap / 3 - 1, dx = l_tap - (l_tap / 3) * 3 - 1;
+            const float *a_tap = a_cur + ((long long)(dy * p.W + dx) * p.lda + (l_cin << 5));
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
-                glds16(ok ? a_ptr[i] + shift : ldm_zero_block + (chunk & 3) * 4, As + (i * 4 + wave) * 256);
+                glds16(ok ? a_tap + a_voff[i] : ldm_zero_block + (chunk & 3) * 4, As + (i * 4 + wave) * 256);
+            }
+            if (++l_cin == p.cpt) {
+                l_cin = 0;
+                ++l_tap;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_F4; ++i) glds16(a_ptr[i] + ((long long)kt << 5), As + (i * 4 + wave) * 256);
+            for (int i = 0; i < A_F4; ++i) glds16(a_cur + a_voff[i], As + (i * 4 + wave) * 256);
+            a_cur += 32;
         }
-        int seg = l_seg_n;
-        long long kcol = (long long)kt << 5;
-        if (p.seg_mode == LDM_SEG_K) {
-            seg = (kt << 5) / p.seg_len;
-            kcol -= (long long)seg * p.seg_len;
-        }
-        const float *wa = (p.use_table ? p.wtab[l_g] : p.w[seg] + l_g * p.w_gstride) + kcol;
-        const float *wb = GATE ? p.w2[seg] + l_g * p.w_gstride + kcol : nullptr;
+        const float *wa = w_row0 + (l_kin << 5);
+        const float *wb = GATE ? w2_row0 + (l_kin << 5) : nullptr;
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const bool second = GATE && (32 * i >= BN);
-            glds16((second ? wb : wa) + b_off[i], Bs + (i * 4 + wave) * 256);
+            glds16((second ? wb : wa) + b_voff[i], Bs + (i * 4 + wave) * 256);
         }
         ++l_step;
         if (++l_kt == nk) {
             l_kt = 0;
             ++l_tile;
             if (l_tile < my_tiles) loader_setup();
+        } else if (++l_kin == seg_steps) {           // next K-segment (LDM_SEG_K): switch weight pointers
+            l_kin = 0;
+            ++l_seg;
+            weight_rows();
         }
     };
 
@@ -137,9 +152,21 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     f32x16 acc[NACC][TM][TN];
     float pre[TM][TN][16];
     f32x4 fa0[TM], fb0[NACC][TN], fa1[TM], fb1[NACC][TN];        // two fragment sets (ping-pong over j)
-    int c_tile = 0, c_kt = 0, c_g = 0, c_m0 = 0, c_n0 = 0;
     if (my_tiles == 0) return;
-    tile_coords(0, c_g, c_m0, c_n0);
+    // accumulators are cleared here and again right after each tile's epilogue -- NOT by a per-step
+    // "c_kt == 0 ? 0 : acc" select, which would put 16 VALU selects per accumulator tile (each waiting
+    // for the previous step's last MFMA) at the head of every K-step and drain the matrix pipe there
+    auto clear_acc = [&]() {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
+    };
+    clear_acc();
 
     auto read_frags = [&](int step, int j, f32x4 (&af)[TM], f32x4 (&bf)[NACC][TN]) {
         const float *As = lds + (step & 1) * STAGE, *Bs = As + BM * 32;
@@ -185,55 +212,50 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     sync_point();
     read_frags(0, 0, fa0, fb0);
 
+    // Tile loop outside, K-steps inside: the accumulators are loop-carried in FIXED registers through a
+    // single-path inner loop (one merged loop with a "last step?" branch made hipcc shuttle all accumulator
+    // registers through v_mov copies behind an s_nop at every K-step, draining the matrix pipe each time).
+    int s = 0;                                            // position in this workgroup's K-step stream
 #pragma unroll 1
-    for (int s = 0; s < total_steps; ++s) {
+    for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
+        int c_g, c_m0, c_n0;
+        tile_coords(c_tile, c_g, c_m0, c_n0);
+        clear_acc();
+#pragma unroll 1
+        for (int kt = 0; kt < nk - 1; ++kt, ++s) {
+            loader_issue();                               // step s+1 (exists: this is not the tile's last step)
+            quarters_0_to_2(s);
+            sync_point();
+            read_frags(s + 1, 0, fa0, fb0);
+            mma(fa1, fb1);
+        }
+        // last K-step of the tile: bias/addend prefetch, MFMAs and epilogue on ONE control path, so the
+        // only wait for the prefetched registers sits in front of their first use
         const bool more = s + 1 < total_steps;
-        if (more) loader_issue();                         // step s+1 -> stage (s+1)&1 (free since the last barrier)
-        if (c_kt == 0) {
+        if (more) loader_issue();
+        const bool use_pre = p.addend != nullptr && p.o_mode == LDM_O_ROWS;
+        const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
+        EpiCols<TN> cols;
+        gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
+        if (use_pre) {
+            const long long gcol = c_g * p.o_gstride;
 #pragma unroll
-            for (int q = 0; q < NACC; ++q)
+            for (int im = 0; im < TM; ++im)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) {
+                        int m = c_m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        m = m < p.M ? m : p.M - 1;
+                        pre[im][jn][e] = p.addend[(long long)m * p.ldadd + gcol + c_n0 + (wn * TN + jn) * 32 + r];
+                    }
         }
-        if (c_kt != nk - 1) {
-            quarters_0_to_2(s);
-            sync_point();
-            if (more) read_frags(s + 1, 0, fa0, fb0);
-            mma(fa1, fb1);
-            ++c_kt;
-        } else {
-            // last K-step of the tile: bias/addend prefetch, MFMAs and epilogue on ONE control path, so the
-            // only wait for the prefetched registers sits in front of their first use
-            const bool use_pre = p.addend != nullptr && p.o_mode == LDM_O_ROWS;
-            const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
-            EpiCols<TN> cols;
-            gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
-            if (use_pre) {
-                const long long gcol = c_g * p.o_gstride;
-#pragma unroll
-                for (int im = 0; im < TM; ++im)
-#pragma unroll
-                    for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            int m = c_m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            m = m < p.M ? m : p.M - 1;
-                            pre[im][jn][e] = p.addend[(long long)m * p.ldadd + gcol + c_n0 + (wn * TN + jn) * 32 + r];
-                        }
-            }
-            quarters_0_to_2(s);
-            sync_point();
-            if (more) read_frags(s + 1, 0, fa0, fb0);
-            mma(fa1, fb1);
-            gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
-            c_kt = 0;
-            ++c_tile;
-            if (c_tile < my_tiles) tile_coords(c_tile, c_g, c_m0, c_n0);
-        }
+        quarters_0_to_2(s);
+        sync_point();
+        if (more) read_frags(s + 1, 0, fa0, fb0);
+        mma(fa1, fb1);
+        gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
+        ++s;
     }
 }
 
@@ -272,20 +294,20 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
     const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
     if (gate) {
         if (amode != LDM_A_ROWS) return 0;
+        static const char *gt = getenv("LDM_GEMM_GATE_TILE");      // experiment knob: "64" -> 64x64 gated tile
+        if (gt && gt[0] == '6' && unit % 64 == 0) return launch_stream<2, 2, 1, 1, true, LDM_A_ROWS>(p, groups, st);
         if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS>(p, groups, st);
         return launch_stream<4, 1, 1, 1, true, LDM_A_ROWS>(p, groups, st);
     }
     // 128x64 output tiles (not 128x128): 96 fewer live registers in the last-step path (no spills at two
     // workgroups per CU), twice the tiles (finer wave quantisation at the deep stages)
     if (amode == LDM_A_CONV3X3) {
-        // measured (tools/gemm_bench.py): the implicit-im2col shapes (long K, per-step tap predicates) run
-        // 8-15 % faster on the tile-per-workgroup kernel; LDM_GEMM_STREAM_CONV=1 forces the stream kernel
-        static const bool force_conv = getenv("LDM_GEMM_STREAM_CONV") != nullptr;
-        if (!force_conv) return 0;
         if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_CONV3X3>(p, groups, st);
         return launch_stream<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch_stream<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+    static const char *pt = getenv("LDM_GEMM_PLAIN_TILE");         // experiment knob: "64" -> 64x64 tile
+    if (pt && pt[0] == '6' && unit % 64 == 0) return launch_stream<2, 2, 1, 1, false, LDM_A_ROWS>(p, groups, st);
     if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
     return launch_stream<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
 }
