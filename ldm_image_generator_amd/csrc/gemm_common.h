@@ -88,6 +88,28 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmP &p, EpiCols<TN> &
     }
 }
 
+// Addend prefetch for o_mode == ROWS (called ahead of the tile's last K-step): one 64-bit base per lane,
+// then compile-time row offsets times the (uniform) row stride.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_prefetch_addend(const GemmP &p, float (&pre)[TM][TN][16], int m0, int n0, int g, int wm, int wn,
+                                                     int r, int h)
+{
+    const int row0 = m0 + wm * TM * 32 + 4 * h;
+    const int lda_ = (int)p.ldadd;
+    const bool full = m0 + WM * TM * 32 <= p.M;
+    const int rclamp = row0 < p.M ? row0 : p.M - 1;
+    const float *base = p.addend + (long long)rclamp * p.ldadd + g * p.o_gstride + n0 + wn * TN * 32 + r;
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int roff = im * 32 + (e & 3) + 8 * (e >> 2);
+            if (!full) roff = row0 + roff < p.M ? roff : (p.M - 1 - rclamp);        // clamp to the last valid row
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) pre[im][jn][e] = base[roff * lda_ + jn * 32];
+        }
+}
+
 template <int WM, int WN, int TM, int TN, bool GATE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int wm, int h,
                                               const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre)
@@ -96,35 +118,73 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x16 (&acc)[GATE
     float b1[TN];
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) b1[jn] = ((c.braw[0][jn] + c.braw[1][jn]) + c.braw[2][jn]) + c.braw[3][jn];
+    auto value = [&](int im, int jn, int e) {
+        float v = acc[0][im][jn][e] + b1[jn];
+        if (GATE) {
+            const float gt = acc[NACC - 1][im][jn][e] + c.b2[jn];
+            v = v * fmaxf(gt, 0.f);
+        } else if (p.act == LDM_ACT_RELU) {
+            v = fmaxf(v, 0.f);
+        } else if (p.act == LDM_ACT_LRELU) {
+            v = v > 0.f ? v : v * p.slope;
+        }
+        // prefetched addend: consumed on every path (also for clamped, non-stored rows) so that the
+        // compiler retires those loads here and never drains the LDS-DMA queue elsewhere for them
+        if (use_pre) v += pre[im][jn][e];
+        return v;
+    };
+    if (p.o_mode == LDM_O_ROWS) {
+        // fast addressing: one 64-bit base per lane + (compile-time row offset) x (uniform 32-bit row stride)
+        const int row0 = m0 + wm * TM * 32 + 4 * h;
+        const int ldo_ = (int)p.ldo, lda_ = (int)p.ldadd;
+        float *obase = p.out + (long long)row0 * p.ldo;
+        const float *abase = p.addend ? p.addend + (long long)row0 * p.ldadd : nullptr;
+        const bool late_add = !use_pre && p.addend != nullptr;
+        if (m0 + WM * TM * 32 <= p.M) {                      // whole tile inside M: no per-element predicate
+#pragma unroll
+            for (int im = 0; im < TM; ++im)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int roff = im * 32 + (e & 3) + 8 * (e >> 2);
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+                        float v = value(im, jn, e);
+                        if (late_add) v += abase[roff * lda_ + c.ocol[jn]];
+                        obase[roff * ldo_ + c.ocol[jn]] = v;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int im = 0; im < TM; ++im)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int roff = im * 32 + (e & 3) + 8 * (e >> 2);
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+                        float v = value(im, jn, e);
+                        if (row0 + roff < p.M) {
+                            if (late_add) v += abase[roff * lda_ + c.ocol[jn]];
+                            obase[roff * ldo_ + c.ocol[jn]] = v;
+                        }
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             const bool live = m < p.M;
-            long long orow0 = m;
-            int ox2 = 0;
-            if (p.o_mode != LDM_O_ROWS) {
-                const int xx = m % p.OW;
-                const int yy = (m / p.OW) % p.OH;
-                const long long bb = m / (p.OW * p.OH);
-                ox2 = 2 * p.OW;
-                orow0 = (bb * 2 * p.OH + 2 * yy) * ox2 + 2 * xx;        // top-left fine pixel
-            }
+            const int xx = m % p.OW;
+            const int yy = (m / p.OW) % p.OH;
+            const long long bb = m / (p.OW * p.OH);
+            const int ox2 = 2 * p.OW;
+            const long long orow0 = (bb * 2 * p.OH + 2 * yy) * ox2 + 2 * xx;        // top-left fine pixel
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
-                float v = acc[0][im][jn][e] + b1[jn];
-                if (GATE) {
-                    const float gt = acc[NACC - 1][im][jn][e] + c.b2[jn];
-                    v = v * fmaxf(gt, 0.f);
-                } else if (p.act == LDM_ACT_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (p.act == LDM_ACT_LRELU) {
-                    v = v > 0.f ? v : v * p.slope;
-                }
-                // prefetched addend: consumed on every path (also for clamped, non-stored rows) so that the
-                // compiler retires those loads here and never drains the LDS-DMA queue elsewhere for them
-                if (use_pre) v += pre[im][jn][e];
+                float v = value(im, jn, e);
                 if (live) {
                     if (p.o_mode == LDM_O_UP2) {
 #pragma unroll
@@ -136,7 +196,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x16 (&acc)[GATE
                         }
                     } else {
                         const long long orow = orow0 + (c.q4[jn] >> 1) * ox2 + (c.q4[jn] & 1);
-                        if (!use_pre && p.addend) v += p.addend[orow * p.ldadd + c.ocol[jn]];
+                        if (p.addend) v += p.addend[orow * p.ldadd + c.ocol[jn]];
                         p.out[orow * p.ldo + c.ocol[jn]] = v;
                     }
                 }

@@ -237,19 +237,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
         EpiCols<TN> cols;
         gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
-        if (use_pre) {
-            const long long gcol = c_g * p.o_gstride;
-#pragma unroll
-            for (int im = 0; im < TM; ++im)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        int m = c_m0 + (wm * TM + im) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        m = m < p.M ? m : p.M - 1;
-                        pre[im][jn][e] = p.addend[(long long)m * p.ldadd + gcol + c_n0 + (wn * TN + jn) * 32 + r];
-                    }
-        }
+        if (use_pre) gemm_prefetch_addend<WM, WN, TM, TN>(p, pre, c_m0, c_n0, c_g, wm, wn, r, h);
         quarters_0_to_2(s);
         sync_point();
         if (more) read_frags(s + 1, 0, fa0, fb0);
