@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
     const int g = blockIdx.y;
     const int ntn = p.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
+    int tile_m, tile_n;
+    tile_from_id(tile, (p.M + BM - 1) / BM, ntn, tile_m, tile_n);
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
     const int chunk = t & 7, lrow = t >> 3;
     const int nk = p.K >> 5;
 

@@ -57,10 +57,10 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     auto tile_coords = [&](int i, int &g, int &m0, int &n0) {
         const int id = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, total_tiles);
         g = id / per_group;
-        const int rem = id - g * per_group;
-        const int tm_ = rem / ntn;
+        int tm_, tn_;
+        tile_from_id(id - g * per_group, ntm, ntn, tm_, tn_);
         m0 = tm_ * BM;
-        n0 = (rem - tm_ * ntn) * BN;
+        n0 = tn_ * BN;
     };
 
     // ---- loader cursor -------------------------------------------------------
