@@ -135,6 +135,12 @@ def main():
                          "launches": launches, "kernel_ms": gemm_ms, "gflop_per_sample_step_measured":
                              None if args.mode != "eval" else gemm_flops / 1e9 / (B * args.steps) / T},
         }
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):      # PMC passes are separate runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): tools/traffic_summary.py
+            tj = json.load(open(tpath))
+            line["roofline"]["traffic"] = tj["gemm_hbm_bytes_per_launch"]
+            line["roofline"]["traffic_unit"] = "bytes per GEMM launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.md)"
+            line["roofline"]["algorithmic_bytes_per_launch"] = None
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64))
         print(json.dumps(line), flush=True)

@@ -1,0 +1,5 @@
+"""Flat-module shim: `import attention` (as the reference's scripts do) resolves to the MI355X-native classes."""
+from ldm_image_generator_amd.attention import *  # noqa: F401,F403
+from ldm_image_generator_amd import attention as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

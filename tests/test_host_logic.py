@@ -114,3 +114,11 @@ def test_sharded_sampling_equals_unsharded_gloo_world2(tmp_path, gb):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_dropin_flat_modules_resolve_to_native_classes():
+    """`from ddpm import DDPM; from vae import Decoder` (sample_ldm.py:1-2) with dropin/ on sys.path."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import unet, vae, ddpm, attention, modules, sinusoidal; "
+            "assert ddpm.DDPM.__module__ == 'ldm_image_generator_amd.ddpm' and vae.Decoder.__module__ == 'ldm_image_generator_amd.vae'; "
+            "assert unet.UNet.__module__ == 'ldm_image_generator_amd.unet'") % (ROOT, os.path.join(ROOT, "ldm_image_generator_amd", "dropin"))
+    subprocess.check_call([sys.executable, "-c", code])

@@ -1,0 +1,54 @@
+"""Summarise the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 --pmc runs as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<tag>_traffic.{md,json}.
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts half the bytes of a wide
+coalesced 16-B/lane stream (global_load and LDS-DMA alike), hence the x2 (guide, section HBM)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(pattern, counter):
+    f = glob.glob(pattern)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        key = name[name.find("gemm"):].split("(")[0] if "gemm" in name else name.split("(")[0][-40:]
+        a = agg[key]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"]) * 1024.0
+        a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return agg
+
+
+if __name__ == "__main__":
+    fetch_dir, write_dir, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    F = per_kernel(fetch_dir + "/*/*counter_collection.csv", "FETCH_SIZE")
+    W = per_kernel(write_dir + "/*/*counter_collection.csv", "WRITE_SIZE")
+    rows, tot = [], [0, 0.0, 0.0]
+    for k in sorted(F, key=lambda k: -F[k][2]):
+        n, fb, ns = F[k]
+        wb = W.get(k, [1, 0.0, 0.0])[1]
+        rows.append(dict(kernel=k, launches=n, fetch_bytes_x2_per_launch=2 * fb / n, write_bytes_per_launch=wb / n,
+                         avg_us=ns / n / 1e3))
+        if "gemm" in k:
+            tot[0] += n
+            tot[1] += 2 * fb + wb
+            tot[2] += ns
+    summary = dict(gemm_launches=tot[0], gemm_hbm_bytes_per_launch=tot[1] / max(tot[0], 1),
+                   gemm_avg_us=tot[2] / max(tot[0], 1) / 1e3, kernels=rows[:12])
+    json.dump(summary, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
+    with open("profiles/%s_traffic.md" % tag, "w") as out:
+        out.write("# HBM-side traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n")
+        out.write("command: `bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline` (B = 256, 2 denoise steps + decode)\n\n")
+        out.write("FETCH_SIZE x2 (gfx950 wide-stream correction), WRITE_SIZE as read.  GEMM family: %d launches, "
+                  "%.1f MB per launch on average, %.1f us per launch (profiled).\n\n" % (tot[0], summary["gemm_hbm_bytes_per_launch"] / 1e6, summary["gemm_avg_us"]))
+        out.write("| kernel | launches | fetch x2 MB/launch | write MB/launch | avg us |\n|---|---|---|---|---|\n")
+        for r in rows[:12]:
+            out.write("| `%s` | %d | %.1f | %.1f | %.1f |\n" % (r["kernel"][:70], r["launches"], r["fetch_bytes_x2_per_launch"] / 1e6,
+                                                           r["write_bytes_per_launch"] / 1e6, r["avg_us"]))
+    print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
