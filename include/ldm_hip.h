@@ -178,6 +178,34 @@ int ldm_nhwc_to_nchw_f32(const float *x, float *out, int B, int C, int HW, void 
 /* sample_ldm.py:75-77: clamp(-1,1) -> *127.5+127.5 -> uint8 truncation, NCHW -> NHWC bytes. */
 int ldm_to_uint8_hwc(const float *img, unsigned char *out, int B, int C, int HW, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training step (ddpm.py:39-48 + autograd of unet.py / modules.py / attention.py).  GEMM-shaped
+ * gradients go through ldm_gemm_f32 (data grads with transposed weights, weight grads as split-K
+ * groups over transposed activations); the entry points below are the non-GEMM pieces.
+ * ------------------------------------------------------------------------------------------------ */
+int ldm_gate_fwd_f32(const float *a, const float *b, float *out, long long n, void *stream);          /* a * relu(b) */
+int ldm_gate_bwd_f32(const float *dh, const float *a, const float *b, float *da, float *db, long long n, void *stream);
+int ldm_relu_bwd_f32(const float *dy, const float *y, float *dx, long long n, void *stream);
+int ldm_add_f32(float *y, const float *x, long long n, void *stream);                                 /* y += x */
+int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulate, void *stream);     /* bias grads */
+int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream);        /* split-K sum */
+/* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) += per (slot, pixel) (atomic) */
+int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, const int *slot, const float *dxf, const float *dres,
+                                 float *dx, float *dfilm, int B, int HW, int C, float eps, void *stream);
+int ldm_avgpool2_bwd_f32(const float *dlo, float *dx, int B, int H, int W, int C, int accumulate, void *stream);
+int ldm_sumpool2_f32(const float *dhi, float *dlo, int B, int H, int W, int C, void *stream);         /* backward of nearest x2 */
+int ldm_stem_bwd_f32(const float *x, const float *dy, float *dw, int B, int Cin, int HW, int C0, void *stream);
+int ldm_head_bwd_f32(const float *x, const float *w, const float *dout, float *dx, float *dw, float *db,
+                     int B, int C0, int HW, int Cin, void *stream);
+/* nn.L1Loss (ddpm.py:16,47): loss[0] = mean |pred - target|; grad = sign(pred - target) * gscale[0] / n */
+int ldm_l1_loss_f32(const float *pred, const float *target, long long n, float *loss, void *stream);
+int ldm_l1_loss_bwd_f32(const float *pred, const float *target, const float *gscale, float *grad, long long n, void *stream);
+/* transposed im2col of the grouped 3x3 conv input: out[g][tap*32+ci][m] (weight gradient of unet.py:30) */
+int ldm_im2col3x3_t_f32(const float *x, float *out, int B, int H, int W, int C, void *stream);
+/* backward of ldm_window_attention_f32: dqkv [B,H,W,3C]; gradients of zero-padded tokens' k, v go to dbias_pad [3C] */
+int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
+                                 float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

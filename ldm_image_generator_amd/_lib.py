@@ -71,6 +71,21 @@ SIGNATURES = {
     "ldm_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "ldm_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "ldm_to_uint8_hwc": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ldm_gate_fwd_f32": (_I, [_P, _P, _P, _L, _P]),
+    "ldm_gate_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    "ldm_relu_bwd_f32": (_I, [_P, _P, _P, _L, _P]),
+    "ldm_add_f32": (_I, [_P, _P, _L, _P]),
+    "ldm_colsum_f32": (_I, [_P, _P, _L, _I, _I, _P]),
+    "ldm_reduce_partials_f32": (_I, [_P, _P, _I, _L, _P]),
+    "ldm_channelnorm_film_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_avgpool2_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ldm_sumpool2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_stem_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_head_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_l1_loss_f32": (_I, [_P, _P, _L, _P, _P]),
+    "ldm_l1_loss_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P]),
+    "ldm_im2col3x3_t_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_window_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

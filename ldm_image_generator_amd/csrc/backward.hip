@@ -1,0 +1,692 @@
+// Backward-pass kernels of the UNet training step (ddpm.py:39-48 + autograd of unet.py / modules.py /
+// attention.py).  All GEMM-shaped gradients reuse ldm_gemm_f32 (data grads: transposed weights; weight
+// grads: transposed activations + split-K over grid groups); this file holds what is not a GEMM.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxV = 8;
+
+__device__ __forceinline__ float group_sum(float v, int lpr)
+{
+    for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+inline int pow2_lanes(int c4n)
+{
+    int lpr = 1;
+    while (lpr < c4n && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+// ---- elementwise ------------------------------------------------------------------------------
+__global__ void gate_fwd_kernel(const f32x4 *a, const f32x4 *b, f32x4 *out, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 av = a[i], bv = b[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = av[e] * fmaxf(bv[e], 0.f);
+    out[i] = o;
+}
+
+__global__ void gate_bwd_kernel(const f32x4 *dh, const f32x4 *a, const f32x4 *b, f32x4 *da, f32x4 *db, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 g = dh[i], av = a[i], bv = b[i];
+    f32x4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        oa[e] = g[e] * fmaxf(bv[e], 0.f);                 // d/da  a*relu(b)
+        ob[e] = bv[e] > 0.f ? g[e] * av[e] : 0.f;         // d/db
+    }
+    da[i] = oa;
+    db[i] = ob;
+}
+
+__global__ void relu_bwd_kernel(const f32x4 *dy, const f32x4 *y, f32x4 *dx, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 g = dy[i], yv = y[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? g[e] : 0.f;
+    dx[i] = o;
+}
+
+__global__ void add_kernel(f32x4 *y, const f32x4 *x, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 a = y[i], b = x[i];
+    y[i] = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+}
+
+// column sums of a row-major [M, N] matrix (bias gradients): 512-row slabs, one atomic per column per slab
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long long M, int N, int slab)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long m0 = (long long)blockIdx.y * slab;
+    const long long m1 = m0 + slab < M ? m0 + slab : M;
+    float s = 0.f;
+    for (long long m = m0; m < m1; ++m) s += x[m * N + n];
+    atomicAdd(out + n, s);
+}
+
+__global__ void reduce_partials_kernel(const float *__restrict__ parts, float *__restrict__ out, int S, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += parts[(long long)k * n + i];
+    out[i] = s;
+}
+
+// ---- ChannelNorm + FiLM backward ----------------------------------------------------------------
+// xf = xn * mul + bias, xn = (x - mean) / sqrt(var_unbiased + eps)
+//   dfilm[slot, pix, c] += dxf * xn ; dfilm[slot, pix, C + c] += dxf            (atomic: samples sharing a slot)
+//   dx = dres + (dxn - mean(dxn) - xn * sum(dxn * xn) / (C - 1)) / den ,  dxn = dxf * mul
+__global__ __launch_bounds__(256) void channelnorm_film_bwd_kernel(const float *__restrict__ x, const float *__restrict__ film,
+                                                                   const int *__restrict__ slot, const float *__restrict__ dxf,
+                                                                   const float *__restrict__ dres, float *__restrict__ dx,
+                                                                   float *__restrict__ dfilm, long long rows, int HW, int C,
+                                                                   float eps, int lpr)
+{
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long row = wave * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const int c4n = C >> 2;
+    const bool live = row < rows;
+    const long long rr = live ? row : 0;
+    const f32x4 *xr = (const f32x4 *)(x + rr * C);
+    const f32x4 *gr = (const f32x4 *)(dxf + rr * C);
+    const int b = (int)(rr / HW), pix = (int)(rr - (long long)b * HW);
+    const int sl = slot ? slot[b] : 0;
+    const long long frow = ((long long)sl * HW + pix) * 2 * C;
+    const f32x4 *fr = (const f32x4 *)(film + frow);
+    f32x4 v[kMaxV], g[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        const bool ok = live && c4 < c4n;
+        v[i] = ok ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = ok ? gr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = group_sum(s, lpr) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i)
+        if (sub + i * lpr < c4n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                ss += d * d;
+            }
+    const float den = sqrtf(group_sum(ss, lpr) / (float)(C - 1) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+            const f32x4 mu = live ? fr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xn = (v[i][e] - mean) / den;
+                const float gx = g[i][e];
+                if (live) {
+                    atomicAdd(dfilm + frow + 4 * c4 + e, gx * xn);
+                    atomicAdd(dfilm + frow + C + 4 * c4 + e, gx);
+                }
+                const float dxn = gx * mu[e];
+                v[i][e] = xn;
+                g[i][e] = dxn;
+                s1 += dxn;
+                s2 += dxn * xn;
+            }
+        }
+    }
+    s1 = group_sum(s1, lpr) / (float)C;
+    s2 = group_sum(s2, lpr) / (float)(C - 1);
+    if (!live) return;
+    const f32x4 *rres = dres ? (const f32x4 *)(dres + row * C) : nullptr;
+    f32x4 *orow = (f32x4 *)(dx + row * C);
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+            f32x4 o = rres ? rres[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += (g[i][e] - s1 - v[i][e] * s2) / den;
+            orow[c4] = o;
+        }
+    }
+}
+
+// ---- pooling ------------------------------------------------------------------------------------
+// backward of AvgPool2d(2): dx[b, 2y+dy, 2x+dx, :] (+)= 0.25 * dlo[b, y, x, :]
+__global__ void avgpool2_bwd_kernel(const f32x4 *__restrict__ dlo, f32x4 *__restrict__ dx, int B, int OH, int OW, int c4n, int accumulate)
+{
+    const long long total = (long long)B * OH * OW * c4n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % c4n);
+    long long r = idx / c4n;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const long long b = r / OH;
+    f32x4 g = dlo[idx];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] *= 0.25f;
+    const int W = 2 * OW;
+    f32x4 *p = dx + ((b * 2 * OH + 2 * oy) * W + 2 * ox) * c4n + c4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        f32x4 *q = p + ((d >> 1) * (long long)W + (d & 1)) * c4n;
+        if (accumulate) {
+            const f32x4 o = *q;
+            *q = f32x4{o[0] + g[0], o[1] + g[1], o[2] + g[2], o[3] + g[3]};
+        } else {
+            *q = g;
+        }
+    }
+}
+
+// backward of nearest Upsample(x2): dlo[b, y, x, :] = sum of the 4 fine gradients
+__global__ void sumpool2_kernel(const f32x4 *__restrict__ dhi, f32x4 *__restrict__ dlo, int B, int OH, int OW, int c4n)
+{
+    const long long total = (long long)B * OH * OW * c4n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % c4n);
+    long long r = idx / c4n;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const long long b = r / OH;
+    const int W = 2 * OW;
+    const f32x4 *p = dhi + ((b * 2 * OH + 2 * oy) * W + 2 * ox) * c4n + c4;
+    const f32x4 a = p[0], bq = p[c4n], c = p[(long long)W * c4n], d = p[(long long)W * c4n + c4n];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ((a[e] + bq[e]) + c[e]) + d[e];
+    dlo[idx] = o;
+}
+
+// ---- stem / head ---------------------------------------------------------------------------------
+// stem: y[m, n] = sum_ci x[b, ci, p] w[n, ci] + bias[n]   ->  dw[n, ci] += sum_m dy[m, n] x[b, ci, p]
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dw,
+                                                       long long M, int Cin, int HW, int C0, int slab)
+{
+    const long long m0 = (long long)blockIdx.x * slab;
+    const long long m1 = m0 + slab < M ? m0 + slab : M;
+    for (int idx = threadIdx.x; idx < C0 * Cin; idx += 256) {
+        const int n = idx / Cin, ci = idx - n * Cin;
+        float s = 0.f;
+        for (long long m = m0; m < m1; ++m) {
+            const long long b = m / HW;
+            const int pix = (int)(m - b * HW);
+            s = fmaf(dy[m * C0 + n], x[(b * Cin + ci) * HW + pix], s);
+        }
+        atomicAdd(dw + idx, s);
+    }
+}
+
+// head: out[b, co, p] = sum_c x[m, c] w[c, co] + bias[co]
+//   dx[m, c] = sum_co dout[b, co, p] w[c, co];  dw[c, co] += sum_m x[m, c] dout[b, co, p];  db[co] += sum dout
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dout,
+                                                       float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db, long long M,
+                                                       int C0, int HW, int Cin)
+{
+    __shared__ float gt[64 * 17];          // dout tile [64 pixels][Cin <= 16]
+    const int t = threadIdx.x;
+    const long long m0 = (long long)blockIdx.x * 64;
+    for (int i = t; i < 64 * Cin; i += 256) {
+        const int co = i / 64, pl = i - co * 64;
+        const long long m = m0 + pl;
+        float v = 0.f;
+        if (m < M) {
+            const long long b = m / HW;
+            v = dout[(b * Cin + co) * HW + (m - b * HW)];
+        }
+        gt[pl * 17 + co] = v;
+    }
+    __syncthreads();
+    // data gradient
+    for (int i = t; i < 64 * C0; i += 256) {
+        const int pl = i / C0, c = i - pl * C0;
+        const long long m = m0 + pl;
+        if (m >= M) continue;
+        float s = 0.f;
+        for (int co = 0; co < Cin; ++co) s = fmaf(gt[pl * 17 + co], w[c * Cin + co], s);
+        dx[m * C0 + c] = s;
+    }
+    // weight / bias gradient partials of this 64-row slab
+    for (int i = t; i < C0 * Cin; i += 256) {
+        const int c = i / Cin, co = i - c * Cin;
+        float s = 0.f;
+        for (int pl = 0; pl < 64; ++pl) {
+            const long long m = m0 + pl;
+            if (m < M) s = fmaf(x[m * C0 + c], gt[pl * 17 + co], s);
+        }
+        atomicAdd(dw + i, s);
+    }
+    if (t < Cin) {
+        float s = 0.f;
+        for (int pl = 0; pl < 64; ++pl) s += gt[pl * 17 + t];
+        atomicAdd(db + t, s);
+    }
+}
+
+// ---- L1 loss (ddpm.py:47 with nn.L1Loss) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float *__restrict__ p, const float *__restrict__ q, long long n, float inv_n,
+                                                      float *__restrict__ loss)
+{
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += fabsf(p[i] - q[i]);
+    s = group_sum(s, 64);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n);
+}
+
+__global__ void l1_loss_bwd_kernel(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ gscale, float inv_n,
+                                   float *__restrict__ grad, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = p[i] - q[i];
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    grad[i] = sgn * gscale[0] * inv_n;
+}
+
+// ---- grouped-conv weight gradient helper: transposed im2col -----------------------------------------
+// out[g][tap*32 + ci][m] = x[(pixel m shifted by tap)][g*32 + ci]  (0 outside the image);  x is [B,H,W,C]
+__global__ __launch_bounds__(256) void im2col3x3_t_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int H, int W, int C)
+{
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z, tap = blockIdx.y;
+    const long long M = (long long)B * H * W;
+    const long long m0 = (long long)blockIdx.x * 32;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {           // row i of the tile = pixel m0 + i, column tx = channel
+        const long long m = m0 + i;
+        float v = 0.f;
+        if (m < M) {
+            const int xx = (int)(m % W), yy = (int)((m / W) % H);
+            if ((unsigned)(yy + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W)
+                v = x[(m + (long long)dy * W + dx) * C + g * 32 + tx];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    float *o = out + ((long long)g * 288 + tap * 32) * M;
+    for (int i = ty; i < 32; i += 8) {           // write row ci = i, contiguous over m
+        const long long m = m0 + tx;
+        if (m < M) o[(long long)i * M + m] = tile[tx][i];
+    }
+}
+
+// ---- window attention backward -----------------------------------------------------------------------
+struct AttnB {
+    const float *qkv, *bias, *xf, *dctx;
+    float *dqkv, *dbias_pad;
+    int B, H, W, C, ws, shift;
+    int Hp, Wp, nwh, nww, heads, L, global;
+    long long total_waves;
+};
+
+__device__ __forceinline__ bool tok_src(const AttnB &p, int wr, int wc, int j, int &sy, int &sx, int &py, int &px)
+{
+    if (p.global) {
+        sy = py = j / p.W;
+        sx = px = j - sy * p.W;
+        return true;
+    }
+    const int wy = j / p.ws, wx = j - wy * p.ws;
+    py = wr * p.ws + wy;
+    px = wc * p.ws + wx;
+    sy = py - p.shift;
+    sy += sy < 0 ? p.Hp : 0;
+    sx = px - p.shift;
+    sx += sx < 0 ? p.Wp : 0;
+    return sy < p.H && sx < p.W;
+}
+
+// One wave per (sample, window, head), lane i = token i (query AND key role).  LDS per wave:
+// K, V, Qs (scaled q), dO : [L][32] each;  P, dS : [L][L+1] each.
+template <int LMAX>
+__global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROW = LMAX * 32, MAT = LMAX * (LMAX + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *Ks = smem + wave * (4 * ROW + 2 * MAT + LMAX);
+    float *Vs = Ks + ROW, *Qs = Vs + ROW, *dOs = Qs + ROW, *Ps = dOs + ROW, *dSs = Ps + MAT, *Kb = dSs + MAT;
+    const int L = p.L, C = p.C;
+    const long long gw = (long long)blockIdx.x * 2 + wave;
+    const bool active = gw < p.total_waves;
+    const int head = (int)(gw % p.heads);
+    const long long t1 = gw / p.heads;
+    const int nwin = p.global ? 1 : p.nwh * p.nww;
+    const int win = (int)(t1 % nwin);
+    const long long b = t1 / nwin;
+    const int wr = win / p.nww, wc = win - wr * p.nww;
+    const long long img = b * p.H * p.W;
+    const float scale = 0.17677669529663687f;
+
+    int sy = 0, sx = 0, py = 0, px = 0;
+    bool ok = false;
+    float qr[32], gr[32];                      // this lane's scaled query and output gradient (registers: no LDS row conflicts)
+#pragma unroll
+    for (int d = 0; d < 32; ++d) qr[d] = gr[d] = 0.f;
+    if (active && lane < L) {
+        ok = tok_src(p, wr, wc, lane, sy, sx, py, px);
+        const long long tokrow = img + (long long)sy * p.W + sx;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 qv, kv, vv, gv;
+            if (ok) {
+                const float *row = p.qkv + tokrow * 3 * C + head * 32 + 4 * c;
+                qv = *(const f32x4 *)row;
+                kv = *(const f32x4 *)(row + C);
+                vv = *(const f32x4 *)(row + 2 * C);
+                gv = *(const f32x4 *)(p.dctx + tokrow * C + head * 32 + 4 * c);
+            } else {
+                qv = *(const f32x4 *)(p.bias + head * 32 + 4 * c);
+                kv = *(const f32x4 *)(p.bias + C + head * 32 + 4 * c);
+                vv = *(const f32x4 *)(p.bias + 2 * C + head * 32 + 4 * c);
+                gv = f32x4{0.f, 0.f, 0.f, 0.f};                       // cropped output: no gradient
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Ks[lane * 32 + 4 * c + e] = kv[e];
+                Vs[lane * 32 + 4 * c + e] = vv[e];
+                qr[4 * c + e] = qv[e] * scale;
+                gr[4 * c + e] = gv[e];
+                Qs[lane * 32 + 4 * c + e] = qr[4 * c + e];
+                dOs[lane * 32 + 4 * c + e] = gv[e];
+            }
+        }
+        float kb = 0.f;
+        if (!p.global) {
+            if (p.shift == 0) {
+                kb = ok ? 0.f : -INFINITY;
+            } else {
+                int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
+                my += my < 0 ? p.Hp : 0;
+                mx += mx < 0 ? p.Wp : 0;
+                kb = (my < p.H && mx < p.W) ? p.xf[(img + (long long)my * p.W + mx) * C] : 0.f;
+            }
+        }
+        Kb[lane] = kb;
+    }
+    __syncthreads();
+    // ---- phase 1 (lane = query i): P[i][:], dS[i][:], dq_i ----------------------------------------
+    if (active && lane < L) {
+        float s[LMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) {
+                float a = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) a = fmaf(qr[d], Ks[j * 32 + d], a);
+                a += Kb[j];
+                s[j] = a;
+                mx = fmaxf(mx, a);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) {
+                s[j] = expf(s[j] - mx);
+                sum += s[j];
+            }
+        float dot = 0.f;
+        float dp[LMAX];
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) {
+                s[j] = s[j] / sum;
+                float a = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) a = fmaf(gr[d], Vs[j * 32 + d], a);
+                dp[j] = a;
+                dot = fmaf(s[j], a, dot);
+            }
+        float dq[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) {
+                const float ds = s[j] * (dp[j] - dot);
+                Ps[lane * (LMAX + 1) + j] = s[j];
+                dSs[lane * (LMAX + 1) + j] = ds;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, Ks[j * 32 + d], dq[d]);
+            }
+        if (ok) {
+            float *o = p.dqkv + (img + (long long)sy * p.W + sx) * 3 * C + head * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                *(f32x4 *)(o + 4 * c) = f32x4{dq[4 * c] * scale, dq[4 * c + 1] * scale, dq[4 * c + 2] * scale, dq[4 * c + 3] * scale};
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 (lane = key j): dk_j = sum_i dS[i][j] qs_i ; dv_j = sum_i P[i][j] dO_i ----------------
+    if (active && lane < L) {
+        float dk[32], dv[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dk[d] = dv[d] = 0.f;
+        for (int i = 0; i < L; ++i) {
+            const float ds = dSs[i * (LMAX + 1) + lane], pp = Ps[i * (LMAX + 1) + lane];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                dk[d] = fmaf(ds, Qs[i * 32 + d], dk[d]);
+                dv[d] = fmaf(pp, dOs[i * 32 + d], dv[d]);
+            }
+        }
+        if (ok) {
+            float *o = p.dqkv + (img + (long long)sy * p.W + sx) * 3 * C + head * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                *(f32x4 *)(o + C + 4 * c) = f32x4{dk[4 * c], dk[4 * c + 1], dk[4 * c + 2], dk[4 * c + 3]};
+                *(f32x4 *)(o + 2 * C + 4 * c) = f32x4{dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]};
+            }
+        } else {                                  // zero-padded token: k, v are the in-proj bias
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                atomicAdd(p.dbias_pad + C + head * 32 + d, dk[d]);
+                atomicAdd(p.dbias_pad + 2 * C + head * 32 + d, dv[d]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+#define EW4_ENTRY(name, kern, ...)                                                                        \
+    LDM_REQUIRE(n > 0 && n % 4 == 0, name ": n must be a positive multiple of 4");                       \
+    hipLaunchKernelGGL(kern, dim3(blocks_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    LDM_CHECK_LAUNCH(name);                                                                               \
+    return LDM_OK;
+
+extern "C" int ldm_gate_fwd_f32(const float *a, const float *b, float *out, long long n, void *stream)
+{
+    LDM_REQUIRE(a && b && out, "ldm_gate_fwd_f32: null pointer");
+    EW4_ENTRY("ldm_gate_fwd_f32", gate_fwd_kernel, (const f32x4 *)a, (const f32x4 *)b, (f32x4 *)out, n / 4)
+}
+
+extern "C" int ldm_gate_bwd_f32(const float *dh, const float *a, const float *b, float *da, float *db, long long n, void *stream)
+{
+    LDM_REQUIRE(dh && a && b && da && db, "ldm_gate_bwd_f32: null pointer");
+    EW4_ENTRY("ldm_gate_bwd_f32", gate_bwd_kernel, (const f32x4 *)dh, (const f32x4 *)a, (const f32x4 *)b, (f32x4 *)da, (f32x4 *)db, n / 4)
+}
+
+extern "C" int ldm_relu_bwd_f32(const float *dy, const float *y, float *dx, long long n, void *stream)
+{
+    LDM_REQUIRE(dy && y && dx, "ldm_relu_bwd_f32: null pointer");
+    EW4_ENTRY("ldm_relu_bwd_f32", relu_bwd_kernel, (const f32x4 *)dy, (const f32x4 *)y, (f32x4 *)dx, n / 4)
+}
+
+extern "C" int ldm_add_f32(float *y, const float *x, long long n, void *stream)
+{
+    LDM_REQUIRE(y && x, "ldm_add_f32: null pointer");
+    EW4_ENTRY("ldm_add_f32", add_kernel, (f32x4 *)y, (const f32x4 *)x, n / 4)
+}
+
+extern "C" int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulate, void *stream)
+{
+    LDM_REQUIRE(x && out && M > 0 && N > 0, "ldm_colsum_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
+        ldm_set_error("ldm_colsum_f32: memset failed");
+        return LDM_ELAUNCH;
+    }
+    const int slab = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, blocks_for(M, slab)), dim3(256), 0, st, x, out, M, N, slab);
+    LDM_CHECK_LAUNCH("ldm_colsum_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream)
+{
+    LDM_REQUIRE(parts && out && S > 0 && n > 0, "ldm_reduce_partials_f32: bad arguments");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, parts, out, S, n);
+    LDM_CHECK_LAUNCH("ldm_reduce_partials_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, const int *slot, const float *dxf, const float *dres,
+                                            float *dx, float *dfilm, int B, int HW, int C, float eps, void *stream)
+{
+    LDM_REQUIRE(x && film && dxf && dx && dfilm, "ldm_channelnorm_film_bwd_f32: null pointer");
+    LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_bwd_f32: bad shape");
+    const int lpr = pow2_lanes(C / 4);
+    const long long rows = (long long)B * HW;
+    const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL(channelnorm_film_bwd_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, dxf, dres,
+                       dx, dfilm, rows, HW, C, eps, lpr);
+    LDM_CHECK_LAUNCH("ldm_channelnorm_film_bwd_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_avgpool2_bwd_f32(const float *dlo, float *dx, int B, int H, int W, int C, int accumulate, void *stream)
+{
+    LDM_REQUIRE(dlo && dx && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "ldm_avgpool2_bwd_f32: bad arguments");
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)dlo, (f32x4 *)dx, B,
+                       H / 2, W / 2, C / 4, accumulate);
+    LDM_CHECK_LAUNCH("ldm_avgpool2_bwd_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_sumpool2_f32(const float *dhi, float *dlo, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(dhi && dlo && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "ldm_sumpool2_f32: bad arguments");
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(sumpool2_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)dhi, (f32x4 *)dlo, B, H / 2,
+                       W / 2, C / 4);
+    LDM_CHECK_LAUNCH("ldm_sumpool2_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_stem_bwd_f32(const float *x, const float *dy, float *dw, int B, int Cin, int HW, int C0, void *stream)
+{
+    LDM_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && HW > 0 && C0 > 0, "ldm_stem_bwd_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, (size_t)C0 * Cin * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_stem_bwd_f32: memset failed"); return LDM_ELAUNCH; }
+    const long long M = (long long)B * HW;
+    const int slab = 256;
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for(M, slab)), dim3(256), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+    LDM_CHECK_LAUNCH("ldm_stem_bwd_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_head_bwd_f32(const float *x, const float *w, const float *dout, float *dx, float *dw, float *db, int B, int C0, int HW,
+                                int Cin, void *stream)
+{
+    LDM_REQUIRE(x && w && dout && dx && dw && db, "ldm_head_bwd_f32: null pointer");
+    LDM_REQUIRE(B > 0 && C0 > 0 && HW > 0 && Cin > 0 && Cin <= 16, "ldm_head_bwd_f32: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, (size_t)C0 * Cin * sizeof(float), st) != hipSuccess || hipMemsetAsync(db, 0, (size_t)Cin * sizeof(float), st) != hipSuccess) {
+        ldm_set_error("ldm_head_bwd_f32: memset failed");
+        return LDM_ELAUNCH;
+    }
+    const long long M = (long long)B * HW;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(M, 64)), dim3(256), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin);
+    LDM_CHECK_LAUNCH("ldm_head_bwd_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_l1_loss_f32(const float *pred, const float *target, long long n, float *loss, void *stream)
+{
+    LDM_REQUIRE(pred && target && loss && n > 0, "ldm_l1_loss_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_l1_loss_f32: memset failed"); return LDM_ELAUNCH; }
+    unsigned blocks = blocks_for(n, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, st, pred, target, n, 1.0f / (float)n, loss);
+    LDM_CHECK_LAUNCH("ldm_l1_loss_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_l1_loss_bwd_f32(const float *pred, const float *target, const float *gscale, float *grad, long long n, void *stream)
+{
+    LDM_REQUIRE(pred && target && gscale && grad && n > 0, "ldm_l1_loss_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, target, gscale, 1.0f / (float)n, grad, n);
+    LDM_CHECK_LAUNCH("ldm_l1_loss_bwd_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_im2col3x3_t_f32(const float *x, float *out, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0, "ldm_im2col3x3_t_f32: bad arguments");
+    const long long M = (long long)B * H * W;
+    LDM_REQUIRE(C / 32 <= 65535, "ldm_im2col3x3_t_f32: too many groups");
+    hipLaunchKernelGGL(im2col3x3_t_kernel, dim3(blocks_for(M, 32), 9, C / 32), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, C);
+    LDM_CHECK_LAUNCH("ldm_im2col3x3_t_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
+                                            float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream)
+{
+    LDM_REQUIRE(qkv && in_proj_bias && dctx && dqkv && dbias_pad, "ldm_window_attention_bwd_f32: null pointer");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0 && ws >= 1 && ws <= 6 && shift >= 0 && shift < ws,
+                "ldm_window_attention_bwd_f32: bad shape (window_size <= 6)");
+    AttnB p{};
+    p.qkv = qkv; p.bias = in_proj_bias; p.xf = xf; p.dctx = dctx; p.dqkv = dqkv; p.dbias_pad = dbias_pad;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.ws = ws; p.shift = shift; p.heads = C / 32;
+    p.global = (H <= ws && W <= ws) ? 1 : 0;
+    if (p.global) {
+        p.Hp = H; p.Wp = W; p.nwh = p.nww = 1; p.L = H * W; p.shift = 0;
+    } else {
+        p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
+        p.nwh = p.Hp / ws; p.nww = p.Wp / ws; p.L = ws * ws;
+        LDM_REQUIRE(shift == 0 || xf != nullptr, "ldm_window_attention_bwd_f32: shift != 0 needs xf");
+    }
+    p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dbias_pad, 0, (size_t)3 * C * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_window_attention_bwd_f32: memset failed"); return LDM_ELAUNCH; }
+    constexpr int LMAX = 36;
+    const size_t smem = 2ull * (4 * LMAX * 32 + 2 * LMAX * (LMAX + 1) + LMAX) * sizeof(float);
+    hipLaunchKernelGGL(window_attention_bwd_kernel<LMAX>, dim3((unsigned)((p.total_waves + 1) / 2)), dim3(128), smem, st, p);
+    LDM_CHECK_LAUNCH("ldm_window_attention_bwd_f32");
+    return LDM_OK;
+}

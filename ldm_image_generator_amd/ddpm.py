@@ -43,7 +43,7 @@ class DDPM(nn.Module):
         self.beta_tilde = torch.Tensor(bt)
 
     def calculate_loss(self, x, condition=None):
-        """ddpm.py:39-48.  The UNet forward runs on the HIP path; see train.py for the backward."""
+        """ddpm.py:39-48.  UNet forward AND backward run on the HIP path (train.py)."""
         t = torch.randint(low=1, high=self.num_timesteps, size=(x.shape[0],))
         alpha_bar_t = torch.index_select(self.alpha_bar, 0, t)
         e = torch.randn(*x.shape, device=x.device)
@@ -53,6 +53,9 @@ class DDPM(nn.Module):
         ops.qsample(x.contiguous().float(), e, sa, sb, xt)
         t = t.to(x.device)
         e_theta = self.model(x=xt, time=t, condition=condition)
+        if type(self.loss_function) is nn.L1Loss and self.loss_function.reduction == "mean":
+            from .train import L1LossFunction          # the default loss, fused fwd/bwd kernels
+            return L1LossFunction.apply(e_theta, e)
         return self.loss_function(e_theta, e)
 
     @torch.no_grad()

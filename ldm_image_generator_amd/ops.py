@@ -14,7 +14,8 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
                    GemmDesc)
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
-           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read",
+           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "reduce_partials", "channelnorm_film_bwd",
+           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
 
@@ -195,3 +196,85 @@ def prof_read():
     n, ms, fl = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
     _lib.check(_lib.load().ldm_prof_read(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "ldm_prof_read")
     return n.value, ms.value, fl.value
+
+
+# ---- training-step entry points (include/ldm_hip.h, "Training step") ---------------------------------
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args, _stream()), name)
+
+
+def gate_fwd(a, b, out):
+    _call("ldm_gate_fwd_f32", _dev(a, "a"), _dev(b, "b"), _dev(out, "out"), a.numel())
+    return out
+
+
+def gate_bwd(dh, a, b, da, db):
+    _call("ldm_gate_bwd_f32", _dev(dh, "dh"), _dev(a, "a"), _dev(b, "b"), _dev(da, "da"), _dev(db, "db"), a.numel())
+
+
+def relu_bwd(dy, y, dx):
+    _call("ldm_relu_bwd_f32", _dev(dy, "dy"), _dev(y, "y"), _dev(dx, "dx"), y.numel())
+    return dx
+
+
+def add_(y, x):
+    _call("ldm_add_f32", _dev(y, "y"), _dev(x, "x"), y.numel())
+    return y
+
+
+def colsum(x, M, N, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    _call("ldm_colsum_f32", _dev(x, "x"), _dev(out, "out"), M, N, int(accumulate))
+    return out
+
+
+def reduce_partials(parts, S, n, out):
+    _call("ldm_reduce_partials_f32", _dev(parts, "parts"), _dev(out, "out"), S, n)
+    return out
+
+
+def channelnorm_film_bwd(x, film, slot, dxf, dres, dx, dfilm, B, HW, C, eps=1e-4):
+    _call("ldm_channelnorm_film_bwd_f32", _dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32), _dev(dxf, "dxf"),
+          _opt(dres, "dres"), _dev(dx, "dx"), _dev(dfilm, "dfilm"), B, HW, C, eps)
+    return dx
+
+
+def avgpool2_bwd(dlo, dx, B, H, W, C, accumulate):
+    _call("ldm_avgpool2_bwd_f32", _dev(dlo, "dlo"), _dev(dx, "dx"), B, H, W, C, int(accumulate))
+    return dx
+
+
+def sumpool2(dhi, dlo, B, H, W, C):
+    _call("ldm_sumpool2_f32", _dev(dhi, "dhi"), _dev(dlo, "dlo"), B, H, W, C)
+    return dlo
+
+
+def stem_bwd(x, dy, dw, B, Cin, HW, C0):
+    _call("ldm_stem_bwd_f32", _dev(x, "x"), _dev(dy, "dy"), _dev(dw, "dw"), B, Cin, HW, C0)
+    return dw
+
+
+def head_bwd(x, w, dout, dx, dw, db, B, C0, HW, Cin):
+    _call("ldm_head_bwd_f32", _dev(x, "x"), _dev(w, "w"), _dev(dout, "dout"), _dev(dx, "dx"), _dev(dw, "dw"), _dev(db, "db"), B, C0, HW, Cin)
+
+
+def l1_loss(pred, target, loss):
+    _call("ldm_l1_loss_f32", _dev(pred, "pred"), _dev(target, "target"), pred.numel(), _dev(loss, "loss"))
+    return loss
+
+
+def l1_loss_bwd(pred, target, gscale, grad):
+    _call("ldm_l1_loss_bwd_f32", _dev(pred, "pred"), _dev(target, "target"), _dev(gscale, "gscale"), _dev(grad, "grad"), pred.numel())
+    return grad
+
+
+def im2col3x3_t(x, out, B, H, W, C):
+    _call("ldm_im2col3x3_t_f32", _dev(x, "x"), _dev(out, "out"), B, H, W, C)
+    return out
+
+
+def window_attention_bwd(qkv, in_proj_bias, xf, dctx, dqkv, dbias_pad, B, H, W, C, ws, shift):
+    _call("ldm_window_attention_bwd_f32", _dev(qkv, "qkv"), _dev(in_proj_bias, "bias"), _opt(xf, "xf"), _dev(dctx, "dctx"),
+          _dev(dqkv, "dqkv"), _dev(dbias_pad, "dbias_pad"), B, H, W, C, ws, shift)

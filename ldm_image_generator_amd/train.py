@@ -1,0 +1,350 @@
+"""Training step of the UNet on the HIP path: forward with saved activations + hand-written backward.
+
+The reference trains through torch autograd (`ddpm.calculate_loss(x).backward()`, train_ldm.py:81-83).
+Here the whole UNet is ONE ``torch.autograd.Function``: its forward runs the same kernels as inference
+(with the ReGLU pre-activations kept), its backward walks a tape in reverse and produces the gradient of
+every parameter that took part in the forward.  Parameters that did not (unselected experts, blocks
+skipped by stochastic depth, the dead cross-attention) get ``None`` -- exactly what autograd gives the
+reference, so AdamW skips them the same way.
+
+Every GEMM-shaped gradient is an ``ldm_gemm_f32`` launch:
+  data gradient    dX = dY . W        -> NT GEMM against the transposed weight (cached per weight version)
+  weight gradient  dW = dY^T . X      -> NT GEMM over transposed activations, split along the huge reduction
+                                         (pixels) into grid groups, partial sums reduced by a second kernel
+"""
+import torch
+
+from . import ops
+
+
+def _T(x, rows=None):
+    """[M, C] -> [C, M] (device transpose kernel)."""
+    m, c = x.shape
+    out = torch.empty(c, m, device=x.device, dtype=torch.float32)
+    ops.nhwc_to_nchw(x, out, 1, c, m)
+    return out
+
+
+class _WeightT:
+    """W [N, K] -> W^T [K, N], cached per parameter version."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, w2d, key_tensor):
+        key = (key_tensor.data_ptr(), key_tensor._version)
+        hit = self.cache.get(id(key_tensor))
+        if hit is None or hit[0] != key:
+            hit = (key, _T(w2d.contiguous()))
+            self.cache[id(key_tensor)] = hit
+        return hit[1]
+
+
+WT = _WeightT()
+
+
+def _w2d(p):
+    return p.detach().reshape(p.shape[0], -1)
+
+
+def _splits(n_out, k_out, m_red):
+    tiles = ((n_out + 127) // 128) * max(k_out // 64, 1)
+    steps = m_red // 32
+    s = 1
+    while tiles * s < 768 and steps % (2 * s) == 0 and steps // (2 * s) >= 4 and s < 256:
+        s *= 2
+    return s
+
+
+def grad_weight(dy_t, x_t, m_red):
+    """dy_t [N, M], x_t [K, M] (M contiguous) -> dW [N, K] = sum_m dy[m, n] x[m, k]."""
+    n_out, k_out = dy_t.shape[0], x_t.shape[0]
+    if m_red % 32:
+        raise ValueError("training path needs the number of rows (%d) to be a multiple of 32" % m_red)
+    s = _splits(n_out, k_out, m_red)
+    ks = m_red // s
+    out = torch.empty(n_out, k_out, device=dy_t.device, dtype=torch.float32)
+    if s == 1:
+        ops.gemm(dy_t, n_out, k_out, ks, [x_t], out, lda=m_red, ldw=m_red)
+        return out
+    parts = torch.empty(s, n_out, k_out, device=dy_t.device, dtype=torch.float32)
+    ops.gemm(dy_t, n_out, k_out, ks, [x_t], parts, lda=m_red, ldw=m_red, groups=s, a_gstride=ks, w_gstride=ks,
+             o_gstride=n_out * k_out)
+    return ops.reduce_partials(parts, s, n_out * k_out, out)
+
+
+class Grads:
+    """parameter -> gradient accumulator for one backward."""
+
+    def __init__(self):
+        self.g = {}
+
+    def add(self, param, grad):
+        grad = grad.reshape(param.shape)
+        if param in self.g:
+            ops.add_(self.g[param], grad.contiguous())
+        else:
+            self.g[param] = grad.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# SwinBlock
+# ------------------------------------------------------------------------------------------------------
+def block_forward(blk, rows, shape, ctx, picks, film, codes, enc_hidden):
+    """unet.py:42-47 with everything the backward needs kept alive."""
+    b, h, w = shape
+    m, c = rows.shape
+    dev = rows.device
+    xf = torch.empty_like(rows)
+    ops.channelnorm_film(rows, film, ctx.slot, xf, b, h * w, c, blk.norm.eps)
+    y = torch.empty_like(rows)
+    ops.gemm(xf, m, 32, 288, [blk._conv_weight()], y, lda=c, ldw=288, biases=[blk.conv.bias.detach()], addend=rows, ldadd=c,
+             ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=32, groups=c // 32, a_gstride=32, w_gstride=32 * 288,
+             o_gstride=32, b_gstride=32)
+    sv = dict(blk=blk, x=rows, xf=xf, film=film, codes=codes, enc_hidden=enc_hidden, picks=picks, shape=shape)
+    if blk.attention_flag:
+        att = blk.self_attention.attention
+        qkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
+        ops.gemm(xf, m, 3 * c, c, [att.in_proj_weight.detach()], qkv, biases=[att.in_proj_bias.detach()])
+        actx = torch.empty(m, c, device=dev, dtype=torch.float32)
+        ops.window_attention(qkv, att.in_proj_bias.detach(), xf, actx, b, h, w, c, blk.self_attention.window_size,
+                             blk.self_attention.shift)
+        ops.gemm(actx, m, c, c, [att.out_proj.weight.detach()], y, biases=[att.out_proj.bias.detach()], addend=y)
+        sv.update(qkv=qkv, actx=actx)
+    regs = [blk.ffn.general] + [blk.ffn.experts[i] for i in picks]
+    f = regs[0].a.weight.shape[0]
+    a_pre = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
+    b_pre = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
+    ops.gemm(xf, m, 3 * f, c, [_w2d(r.a.weight) for r in regs], a_pre, biases=[r.a.bias.detach() for r in regs])
+    ops.gemm(xf, m, 3 * f, c, [_w2d(r.b.weight) for r in regs], b_pre, biases=[r.b.bias.detach() for r in regs])
+    hid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
+    ops.gate_fwd(a_pre, b_pre, hid)
+    ops.gemm(hid, m, c, 3 * f, [_w2d(r.c.weight) for r in regs], y, biases=[r.c.bias.detach() for r in regs],
+             seg_mode=ops.SEG_K, addend=y)
+    sv.update(regs=regs, a_pre=a_pre, b_pre=b_pre, hid=hid)
+    return y, sv
+
+
+def block_backward(sv, dy, ctx, grads):
+    blk, x, xf, shape = sv["blk"], sv["x"], sv["xf"], sv["shape"]
+    b, h, w = shape
+    m, c = x.shape
+    dev = x.device
+    regs = sv["regs"]
+    f = regs[0].a.weight.shape[0]
+    dy_t = _T(dy)
+    xf_t = _T(xf)
+    bias_dy = ops.colsum(dy, m, c)
+    # ---- RandomMoE: y += sum_e c_e(a_e(xf) * relu(b_e(xf))) ----------------------------------------------
+    dwc = grad_weight(dy_t, _T(sv["hid"]), m)                       # [C, 3F]
+    dhid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
+    ops.gemm(dy, m, 3 * f, c, [WT.get(_w2d(r.c.weight), r.c.weight) for r in regs], dhid)
+    da = torch.empty_like(dhid)
+    db = torch.empty_like(dhid)
+    ops.gate_bwd(dhid, sv["a_pre"], sv["b_pre"], da, db)
+    dxf = torch.empty(m, c, device=dev, dtype=torch.float32)
+    ops.gemm(da, m, c, 3 * f, [WT.get(_w2d(r.a.weight), r.a.weight) for r in regs], dxf, seg_mode=ops.SEG_K)
+    ops.gemm(db, m, c, 3 * f, [WT.get(_w2d(r.b.weight), r.b.weight) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)
+    dwa = grad_weight(_T(da), xf_t, m)                              # [3F, C]
+    dwb = grad_weight(_T(db), xf_t, m)
+    dba, dbb = ops.colsum(da, m, 3 * f), ops.colsum(db, m, 3 * f)
+    for e, r in enumerate(regs):
+        grads.add(r.c.weight, dwc[:, e * f:(e + 1) * f])
+        grads.add(r.c.bias, bias_dy.clone())
+        grads.add(r.a.weight, dwa[e * f:(e + 1) * f])
+        grads.add(r.b.weight, dwb[e * f:(e + 1) * f])
+        grads.add(r.a.bias, dba[e * f:(e + 1) * f])
+        grads.add(r.b.bias, dbb[e * f:(e + 1) * f])
+    # ---- window attention ------------------------------------------------------------------------------
+    if blk.attention_flag:
+        att = blk.self_attention.attention
+        dctx = torch.empty(m, c, device=dev, dtype=torch.float32)
+        ops.gemm(dy, m, c, c, [WT.get(att.out_proj.weight.detach(), att.out_proj.weight)], dctx)
+        grads.add(att.out_proj.weight, grad_weight(dy_t, _T(sv["actx"]), m))
+        grads.add(att.out_proj.bias, bias_dy.clone())
+        dqkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
+        dpad = torch.empty(3 * c, device=dev, dtype=torch.float32)
+        ops.window_attention_bwd(sv["qkv"], att.in_proj_bias.detach(), xf, dctx, dqkv, dpad, b, h, w, c,
+                                 blk.self_attention.window_size, blk.self_attention.shift)
+        ops.gemm(dqkv, m, c, 3 * c, [WT.get(att.in_proj_weight.detach(), att.in_proj_weight)], dxf, addend=dxf)
+        grads.add(att.in_proj_weight, grad_weight(_T(dqkv), xf_t, m))
+        grads.add(att.in_proj_bias, ops.add_(ops.colsum(dqkv, m, 3 * c), dpad))
+    # ---- grouped 3x3 conv ------------------------------------------------------------------------------
+    g = c // 32
+    wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
+    # data gradient = conv of dy with the spatially flipped, in/out-swapped filter: [g, ci, (flipped tap), co]
+    wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
+    ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
+             cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
+    xcol_t = torch.empty(g, 288, m, device=dev, dtype=torch.float32)
+    ops.im2col3x3_t(xf, xcol_t, b, h, w, c)
+    dwconv = torch.empty(g, 32, 288, device=dev, dtype=torch.float32)
+    for gi in range(g):
+        dwconv[gi] = grad_weight(dy_t[gi * 32:(gi + 1) * 32], xcol_t[gi], m)
+    grads.add(blk.conv.weight, dwconv.reshape(c, 3, 3, 32).permute(0, 3, 1, 2))
+    grads.add(blk.conv.bias, bias_dy.clone())
+    # ---- ChannelNorm + FiLM, residual -------------------------------------------------------------------
+    film = sv["film"]
+    dfilm = torch.zeros_like(film)
+    dx = torch.empty_like(x)
+    ops.channelnorm_film_bwd(x, film, ctx.slot, dxf, dy, dx, dfilm, b, h * w, c, blk.norm.eps)
+    encodings_backward(blk.encodings, sv["codes"], sv["enc_hidden"], dfilm, grads)
+    return dx
+
+
+def encodings_forward(enc, codes):
+    """unet.py:20 keeping the hidden activation.  codes [Mf, 2C] (Mf padded to a multiple of 32 with zero rows)."""
+    m, c = codes.shape[0], enc.channels
+    hid = torch.empty(m, 4 * c, device=codes.device, dtype=torch.float32)
+    ops.gemm(codes, m, 4 * c, 2 * c, [_w2d(enc.proj1.weight)], hid, biases=[enc.proj1.bias.detach()], act=ops.ACT_RELU)
+    film = torch.empty(m, 2 * c, device=codes.device, dtype=torch.float32)
+    ops.gemm(hid, m, 2 * c, 4 * c, [_w2d(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
+    return hid, film
+
+
+def encodings_backward(enc, codes, hid, dfilm, grads):
+    m, c = codes.shape[0], enc.channels
+    mp = (m + 31) // 32 * 32
+    if mp != m:           # pad the (small) FiLM-side matrices with zero rows so the reduction length is a multiple of 32
+        def pad(t):
+            out = torch.zeros(mp, t.shape[1], device=t.device, dtype=torch.float32)
+            out[:m] = t
+            return out
+        codes, hid, dfilm = pad(codes), pad(hid), pad(dfilm)
+    grads.add(enc.proj2.weight, grad_weight(_T(dfilm), _T(hid), mp))
+    grads.add(enc.proj2.bias, ops.colsum(dfilm, mp, 2 * c))
+    dh = torch.empty(mp, 4 * c, device=codes.device, dtype=torch.float32)
+    ops.gemm(dfilm, mp, 4 * c, 2 * c, [WT.get(_w2d(enc.proj2.weight), enc.proj2.weight)], dh)
+    ops.relu_bwd(dh, hid, dh)
+    grads.add(enc.proj1.weight, grad_weight(_T(dh), _T(codes), mp))
+    grads.add(enc.proj1.bias, ops.colsum(dh, mp, 4 * c))
+
+
+# ------------------------------------------------------------------------------------------------------
+# whole UNet
+# ------------------------------------------------------------------------------------------------------
+class UNetFunction(torch.autograd.Function):
+    """unet.py:89-103 forward + backward on the HIP path.  ``params`` only anchors the graph."""
+
+    @staticmethod
+    def forward(fctx, net, x, time, *params):
+        from .unet import TimeContext
+        b, cin, h, w = x.shape
+        if (b * h * w) % 32 or ((b * h * w) >> (2 * (len(net.channels) - 1))) % 32:
+            raise ValueError("training path: B*H*W at every level must be a multiple of 32")
+        dev = x.device
+        ctx = TimeContext(time, b, dev)
+        order = [blk for l in net.encoder_stages for blk in l.stage.blocks] + [blk for l in net.decoder_stages for blk in l.stage.blocks]
+        decisions = {blk: blk.draw() for blk in order}
+        tape = []
+        c0 = net.channels[0]
+        x = x.contiguous().float()
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x, _w2d(net.encoder_first.weight), net.encoder_first.bias.detach(), rows, b, cin, h * w, c0)
+
+        def run_stage(stage, rows, shape):
+            for blk in stage.blocks:
+                picks = decisions[blk]
+                if picks is None:
+                    continue
+                codes = ctx.codes(rows.shape[1], shape[1], shape[2])
+                enc_hidden, film = encodings_forward(blk.encodings, codes)
+                rows, sv = block_forward(blk, rows, shape, ctx, picks, film, codes, enc_hidden)
+                tape.append(("block", sv))
+            return rows
+
+        skips = []
+        n = len(net.encoder_stages)
+        for i, l in enumerate(net.encoder_stages):
+            rows = run_stage(l.stage, rows, (b, h, w))
+            if i == n - 1:
+                skips.insert(0, None)
+            else:
+                skips.insert(0, rows)
+                conv = l.ch_conv[0]
+                pooled = torch.empty(b * (h // 2) * (w // 2), rows.shape[1], device=dev, dtype=torch.float32)
+                ops.avgpool2(rows, pooled, b, h, w, rows.shape[1])
+                h, w = h // 2, w // 2
+                rows = torch.empty(b * h * w, conv.weight.shape[0], device=dev, dtype=torch.float32)
+                ops.gemm(pooled, b * h * w, conv.weight.shape[0], pooled.shape[1], [_w2d(conv.weight)], rows, biases=[conv.bias.detach()])
+                tape.append(("down", dict(conv=conv, pooled=pooled, shape=(b, h, w), level=i)))
+        for j, (l, s) in enumerate(zip(net.decoder_stages, skips)):
+            if not isinstance(l.ch_conv, torch.nn.Identity):
+                conv = l.ch_conv[1]
+                up = torch.empty(b * 4 * h * w, conv.weight.shape[0], device=dev, dtype=torch.float32)
+                ops.gemm(rows, b * h * w, conv.weight.shape[0], rows.shape[1], [_w2d(conv.weight)], up, biases=[conv.bias.detach()],
+                         addend=s, o_mode=ops.O_UP2, out_hw=(h, w))
+                tape.append(("up", dict(conv=conv, lo=rows, shape=(b, h, w), level=n - 1 - j)))
+                h, w = 2 * h, 2 * w
+                rows = up
+            rows = run_stage(l.stage, rows, (b, h, w))
+        out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
+        wl = net.decoder_last.weight.detach().reshape(c0, cin)
+        ops.head_nchw(rows, wl, net.decoder_last.bias.detach(), out, b, c0, h * w, cin)
+        fctx.net, fctx.tape, fctx.tctx, fctx.x, fctx.last_rows, fctx.params = net, tape, ctx, x, rows, params
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        net, tape, ctx, x, params = fctx.net, fctx.tape, fctx.tctx, fctx.x, fctx.params
+        b, cin, h, w = x.shape
+        dev = x.device
+        grads = Grads()
+        c0 = net.channels[0]
+        rows = fctx.last_rows
+        drows = torch.empty_like(rows)
+        dwl = torch.empty(c0, cin, device=dev, dtype=torch.float32)
+        dbl = torch.empty(cin, device=dev, dtype=torch.float32)
+        ops.head_bwd(rows, net.decoder_last.weight.detach().reshape(c0, cin), dout.contiguous().float(), drows, dwl, dbl, b, c0, h * w, cin)
+        grads.add(net.decoder_last.weight, dwl)
+        grads.add(net.decoder_last.bias, dbl)
+        dskip = {}
+        for kind, sv in reversed(tape):
+            if kind == "block":
+                drows = block_backward(sv, drows, ctx, grads)
+            elif kind == "up":
+                conv, lo, (bb, lh, lw) = sv["conv"], sv["lo"], sv["shape"]
+                cn = conv.weight.shape[0]
+                dskip[sv["level"]] = drows                                  # gradient of the additive skip (unet.py:101)
+                dlo = torch.empty(bb * lh * lw, cn, device=dev, dtype=torch.float32)
+                ops.sumpool2(drows, dlo, bb, 2 * lh, 2 * lw, cn)
+                mlo = bb * lh * lw
+                grads.add(conv.weight, grad_weight(_T(dlo), _T(lo), mlo))
+                grads.add(conv.bias, ops.colsum(dlo, mlo, cn))
+                drows = torch.empty(mlo, lo.shape[1], device=dev, dtype=torch.float32)
+                ops.gemm(dlo, mlo, lo.shape[1], cn, [WT.get(_w2d(conv.weight), conv.weight)], drows)
+            elif kind == "down":
+                conv, pooled, (bb, lh, lw) = sv["conv"], sv["pooled"], sv["shape"]
+                mlo = bb * lh * lw
+                grads.add(conv.weight, grad_weight(_T(drows), _T(pooled), mlo))
+                grads.add(conv.bias, ops.colsum(drows, mlo, conv.weight.shape[0]))
+                dpool = torch.empty(mlo, pooled.shape[1], device=dev, dtype=torch.float32)
+                ops.gemm(drows, mlo, pooled.shape[1], conv.weight.shape[0], [WT.get(_w2d(conv.weight), conv.weight)], dpool)
+                hi = dskip.pop(sv["level"]).clone()                         # start from the skip gradient, add the pooled path
+                ops.avgpool2_bwd(dpool, hi, bb, 2 * lh, 2 * lw, pooled.shape[1], True)
+                drows = hi
+        dw0 = torch.empty(c0, cin, device=dev, dtype=torch.float32)
+        ops.stem_bwd(x, drows, dw0, b, cin, h * w, c0)
+        grads.add(net.encoder_first.weight, dw0)
+        grads.add(net.encoder_first.bias, ops.colsum(drows, b * h * w, c0))
+        fctx.tape = None
+        return (None, None, None) + tuple(grads.g.get(p) for p in params)
+
+
+class L1LossFunction(torch.autograd.Function):
+    """nn.L1Loss() (mean reduction) of ddpm.py:16,47 as two kernels."""
+
+    @staticmethod
+    def forward(fctx, pred, target):
+        pred, target = pred.contiguous().float(), target.contiguous().float()
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        ops.l1_loss(pred, target, loss)
+        fctx.save_for_backward(pred, target)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(fctx, gout):
+        pred, target = fctx.saved_tensors
+        grad = torch.empty_like(pred)
+        ops.l1_loss_bwd(pred, target, gout.reshape(1).contiguous().float(), grad)
+        return grad, None

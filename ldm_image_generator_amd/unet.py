@@ -232,6 +232,11 @@ class UNet(nn.Module):
         return films
 
     def forward(self, x, time, condition=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training step: same kernels + saved activations, hand-written backward (train.py)
+            from .train import UNetFunction
+            params = [p for p in self.parameters() if p.requires_grad]
+            return UNetFunction.apply(self, x, time, *params)
         b, cin, h, w = x.shape
         dev = x.device
         ctx = TimeContext(time, b, dev, uniform=self._uniform_time)

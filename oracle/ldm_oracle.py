@@ -183,7 +183,8 @@ def window_attention(sd, p, x, window_size=6, shift=0):
         xr = torch.roll(xp, (shift, shift), (2, 3))       # :39
         # :40 assigns roll(x) to ``mask``: a FLOAT tensor, rolled twice in total.
         bias_map = torch.roll(xr, (shift, shift), (2, 3))[:, 0:1]       # channel 0 is what :81 keeps
-        key_bias = _to_windows(bias_map, ws).reshape(-1, ws * ws)
+        # attention.py:76-81 slices the mask under torch.no_grad(): no gradient flows through it
+        key_bias = _to_windows(bias_map, ws).reshape(-1, ws * ws).detach()
         xp = xr
     else:
         m = torch.zeros(1, 1, hp, wp, dtype=torch.bool)   # :31-35

@@ -229,3 +229,21 @@ def test_ddim_sample_full_size():
     x0 = O.ddim_sample(sd, (1, 8, 32, 32), seed=0, num_steps=50, training=True, prefix="")
     ref = T(g["x0_train_50"])
     assert rel_l2(x0, ref) < 1e-4 and max_rel(x0, ref) < 1e-3
+
+
+def test_ddpm_loss_gradients_tiny():
+    """Autograd through the oracle reproduces the reference's per-parameter gradient norms (incl. which
+    parameters get no gradient at all, and the detached float mask of the shifted windows)."""
+    g = load_golden("loss_tiny")
+    sd = {k: v.requires_grad_() for k, v in O.formula_state(O.unet_state_shapes(8, **TINY)).items()}
+    random.seed(3)
+    loss = O.ddpm_loss(sd, T(g["x"]), t=T(g["t"]), e=T(g["e"]), training=True, unet_kwargs=TINY, prefix="")
+    loss.backward()
+    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
+    for k, v in sd.items():
+        ref = norms[k]
+        if ref < 0:
+            assert v.grad is None, k
+        else:
+            assert abs(float(v.grad.double().norm()) - ref) < 1e-5 * max(ref, 1e-9) + 1e-12, k
+    assert rel_l2(sd["encoder_first.weight"].grad, T(g["grad_encoder_first_weight"])) < 1e-5
