@@ -74,3 +74,41 @@ def sample_images_sharded(sample_fn, decode_fn, global_batch, latent_shape, seed
     x_t = global_noise(global_batch, latent_shape, seed)[lo:hi].to(device)
     images = decode_fn(sample_fn(x_t))
     return gather_images(images, global_batch, rank, world) if gather else images
+
+
+# ------------------------------------------------------------------------------------------------------
+# data-parallel training (BASELINE cfg 5): replicas + ONE gradient all-reduce per step
+# ------------------------------------------------------------------------------------------------------
+def allreduce_gradients(params, world):
+    """Average the gradients of the parameters that took part in this step with a single flat all-reduce.
+
+    Every rank seeds Python's ``random`` identically before ``calculate_loss`` (the reference draws ONE set of
+    stochastic-depth / expert decisions per step for its whole batch), so the set of parameters with a
+    gradient is the same on every rank and no "used" flags have to travel.  Unused parameters keep
+    ``grad is None`` and are skipped by AdamW exactly as in the single-process reference.
+    """
+    used = [p for p in params if p.grad is not None]
+    if world == 1 or not used:
+        return len(used)
+    flat = torch.cat([p.grad.reshape(-1) for p in used])            # one bucket: 288 GB of HBM, point-to-point xGMI
+    dist.all_reduce(flat, op=dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM)
+    if not flat.is_cuda:
+        flat /= world                                                # gloo (CPU tests) has no AVG
+    off = 0
+    for p in used:
+        n = p.numel()
+        p.grad = flat[off:off + n].view_as(p)
+        off += n
+    return len(used)
+
+
+def train_step(ddpm, optimizer, x_local, step_seed, world):
+    """One optimisation step of train_ldm.py:76-86 on this rank's shard of the global batch."""
+    import random
+    random.seed(step_seed)                                           # identical expert / depth decisions on all ranks
+    optimizer.zero_grad()
+    loss = ddpm.calculate_loss(x_local)
+    loss.backward()
+    allreduce_gradients(list(ddpm.parameters()), world)
+    optimizer.step()
+    return loss

@@ -122,3 +122,29 @@ def test_dropin_flat_modules_resolve_to_native_classes():
             "assert ddpm.DDPM.__module__ == 'ldm_image_generator_amd.ddpm' and vae.Decoder.__module__ == 'ldm_image_generator_amd.vae'; "
             "assert unet.UNet.__module__ == 'ldm_image_generator_amd.unet'") % (ROOT, os.path.join(ROOT, "ldm_image_generator_amd", "dropin"))
     subprocess.check_call([sys.executable, "-c", code])
+
+
+GRAD_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from ldm_image_generator_amd import dist as ld
+rank, world, _ = ld.init_from_env(backend="gloo")
+ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+ps[0].grad = torch.full((3, 4), float(rank + 1)); ps[2].grad = torch.arange(4.).reshape(2, 2) * (rank + 1)   # ps[1] unused
+n = ld.allreduce_gradients(ps, world)
+assert n == 2 and ps[1].grad is None
+assert torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[2].grad, torch.arange(4.).reshape(2, 2) * 1.5)
+import torch.distributed as dist
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_gradient_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "g.py"
+    script.write_text(GRAD_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
