@@ -230,8 +230,6 @@ class UNetFunction(torch.autograd.Function):
     def forward(fctx, net, x, time, *params):
         from .unet import TimeContext
         b, cin, h, w = x.shape
-        if (b * h * w) % 32 or ((b * h * w) >> (2 * (len(net.channels) - 1))) % 32:
-            raise ValueError("training path: B*H*W at every level must be a multiple of 32")
         dev = x.device
         ctx = TimeContext(time, b, dev)
         order = [blk for l in net.encoder_stages for blk in l.stage.blocks] + [blk for l in net.decoder_stages for blk in l.stage.blocks]

@@ -7,8 +7,8 @@ dense 3x3 as implicit GEMM with fused bias + leaky_relu (+ residual),
 ConvTranspose2d(2,2) as one GEMM with a 2x2 scatter epilogue; ``to_rgb`` and the
 bilinear RGB accumulation are one fused HBM-bound kernel per stage.
 
-``Encoder``, ``VectorQuantizer``, ``Discriminator`` and ``VAE.calclate_loss`` (VAE
-training) are outside the hot path and are not provided.
+``Encoder`` (latent pre-encoding for train_ldm.py) reuses the same kernels.  ``VectorQuantizer``,
+``Discriminator`` and ``VAE.calclate_loss`` (VAE training) are outside the hot path and are not provided.
 """
 import torch
 import torch.nn as nn
@@ -68,6 +68,63 @@ class ResBlock(nn.Module):
     def forward(self, x):
         rows, shape = to_rows(x)
         return from_rows(self.forward_rows(rows, shape), shape)
+
+
+class ResStack(nn.Module):
+    """vae.py:68-74."""
+
+    def __init__(self, channels, num_layers=2):
+        super().__init__()
+        self.seq = nn.Sequential(*[ResBlock(channels) for _ in range(num_layers)])
+
+    def forward_rows(self, rows, shape):
+        for blk in self.seq:
+            rows = blk.forward_rows(rows, shape)
+        return rows
+
+    def forward(self, x):
+        rows, shape = to_rows(x)
+        return from_rows(self.forward_rows(rows, shape), shape)
+
+
+class Encoder(nn.Module):
+    """vae.py:76-96: image -> latent (used by train_ldm.py to pre-encode the training set).
+    Same kernels as the decoder: stem 1x1 from NCHW, dense 3x3 implicit GEMMs, avg-pool + 1x1 GEMM, and the
+    NHWC->NCHW head kernel for the 8-channel output."""
+
+    def __init__(self, input_channels=3, latent_channels=8, channels=[64, 128, 256, 512], stages=[2, 2, 2, 2]):
+        super().__init__()
+        self.input_layer = nn.Conv2d(input_channels, channels[0], 1, 1, 0)
+        self.output_layer = nn.Conv2d(channels[-1], latent_channels, 1, 1, 0)
+        self.stages = nn.ModuleList([ResStack(c, l) for c, l in zip(channels, stages)])
+        self.downsamples = nn.ModuleList([])
+        for i, c in enumerate(channels):
+            if i == len(self.stages) - 1:
+                self.downsamples.append(nn.Identity())
+            else:
+                self.downsamples.append(nn.Sequential(nn.AvgPool2d(kernel_size=2), nn.Conv2d(c, channels[i + 1], 1, 1, 0)))
+        self._out_t = _PackedWeight(lambda w: w.reshape(w.shape[0], -1).t())          # [C, latent] for the head kernel
+
+    def forward(self, x):
+        b, cin, h, w = x.shape
+        dev = x.device
+        c0 = self.input_layer.weight.shape[0]
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x.contiguous().float(), w2d(self.input_layer), self.input_layer.bias.detach(), rows, b, cin, h * w, c0)
+        for stage, down in zip(self.stages, self.downsamples):
+            rows = stage.forward_rows(rows, (b, h, w))
+            if not isinstance(down, nn.Identity):
+                conv = down[1]
+                c = rows.shape[1]
+                pooled = torch.empty(b * (h // 2) * (w // 2), c, device=dev, dtype=torch.float32)
+                ops.avgpool2(rows, pooled, b, h, w, c)
+                h, w = h // 2, w // 2
+                rows = torch.empty(b * h * w, conv.weight.shape[0], device=dev, dtype=torch.float32)
+                ops.gemm(pooled, b * h * w, conv.weight.shape[0], c, [w2d(conv)], rows, biases=[conv.bias.detach()])
+        cz = self.output_layer.weight.shape[0]
+        z = torch.empty(b, cz, h, w, device=dev, dtype=torch.float32)
+        ops.head_nchw(rows, self._out_t.get(self.output_layer.weight), self.output_layer.bias.detach(), z, b, rows.shape[1], h * w, cz)
+        return z
 
 
 class DecoderStack(nn.Module):
@@ -134,6 +191,10 @@ class VAE(nn.Module):
         self.encoder = encoder
         self.decoder = decoder
         self.quantizer = quantizer
+
+    @torch.no_grad()
+    def encode(self, x):
+        return self.encoder(x)
 
     @torch.no_grad()
     def decode(self, z):

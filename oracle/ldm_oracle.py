@@ -356,6 +356,33 @@ def vae_decode(sd, z, stages=(2, 2, 2, 2), prefix=""):
     return rgb_out
 
 
+def vae_encode(sd, x, stages=(2, 2, 2, 2), prefix=""):
+    """vae.py:91-96 (Encoder.forward): 1x1 in -> per stage [ResBlocks -> AvgPool2d(2) -> 1x1] -> 1x1 out."""
+    p = prefix
+    y = _pointwise(x, sd[p + "input_layer.weight"], sd[p + "input_layer.bias"])
+    for s, nblk in enumerate(stages):
+        for k in range(nblk):
+            y = res_block(sd, "%sstages.%d.seq.%d." % (p, s, k), y)
+        if s < len(stages) - 1:
+            q = "%sdownsamples.%d.1." % (p, s)
+            y = _pointwise(F.avg_pool2d(y, 2), sd[q + "weight"], sd[q + "bias"])
+    return _pointwise(y, sd[p + "output_layer.weight"], sd[p + "output_layer.bias"])
+
+
+def encoder_state_shapes(input_channels=3, latent_channels=8, channels=(64, 128, 256, 512), stages=(2, 2, 2, 2), prefix=""):
+    out = {}
+    p = prefix
+    _conv_keys(out, p + "input_layer.", channels[0], input_channels)
+    _conv_keys(out, p + "output_layer.", latent_channels, channels[-1])
+    for s, c in enumerate(channels):
+        for k in range(stages[s]):
+            _conv_keys(out, "%sstages.%d.seq.%d.c1." % (p, s, k), c, c, 3)
+            _conv_keys(out, "%sstages.%d.seq.%d.c2." % (p, s, k), c, c, 3)
+    for s in range(len(channels) - 1):
+        _conv_keys(out, "%sdownsamples.%d.1." % (p, s), channels[s + 1], channels[s])
+    return out
+
+
 def to_uint8_hwc(img):
     """sample_ldm.py:75-77: clamp(-1,1) -> *127.5+127.5 -> uint8 TRUNCATION -> HWC."""
     img = torch.clamp(img, -1, 1)

@@ -281,7 +281,20 @@ def vae_cases():
          y_norm=y.double().norm(), y_mean=y.double().mean(dim=(0, 2, 3)), u8_rows=u8[100:104])
 
 
+@torch.no_grad()
+def encoder_cases():
+    enc = load_formula(ref_vae.Encoder(channels=[32, 64, 32], stages=[1, 2, 1]))
+    x = g("enc.x", (2, 3, 16, 24))
+    save("encoder_tiny", x=x, z=enc(x))
+    full = load_formula(ref_vae.Encoder())
+    x = g("encfull.x", (1, 3, 128, 128))
+    save("encoder_full", x=x, z=full(x))
+
+
 if __name__ == "__main__":
+    if "--encoder-only" in sys.argv:
+        encoder_cases()
+        sys.exit(0)
     tables()
     schedule()
     module_cases()
@@ -289,3 +302,4 @@ if __name__ == "__main__":
     sample_cases(tiny, full)
     loss_cases(tiny)
     vae_cases()
+    encoder_cases()

@@ -247,3 +247,15 @@ def test_ddpm_loss_gradients_tiny():
         else:
             assert abs(float(v.grad.double().norm()) - ref) < 1e-5 * max(ref, 1e-9) + 1e-12, k
     assert rel_l2(sd["encoder_first.weight"].grad, T(g["grad_encoder_first_weight"])) < 1e-5
+
+
+def test_encoder_tiny_and_full():
+    g = load_golden("encoder_tiny")
+    cfg = dict(channels=(32, 64, 32), stages=(1, 2, 1))
+    sd = O.formula_state(O.encoder_state_shapes(**cfg))
+    assert rel_l2(O.vae_encode(sd, T(g["x"]), stages=cfg["stages"]), T(g["z"])) < TOL
+    g = load_golden("encoder_full")
+    shapes = O.encoder_state_shapes()
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 12714888
+    with torch.no_grad():
+        assert rel_l2(O.vae_encode(O.formula_state(shapes), T(g["x"])), T(g["z"])) < TOL
