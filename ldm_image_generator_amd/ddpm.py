@@ -79,11 +79,13 @@ class DDPM(nn.Module):
         alpha = torch.cumprod((1 - self.beta), dim=0)
         bar = tqdm(total=len(steps), disable=not progress)
         hint_ok = hasattr(self.model, "_uniform_time")
+        t_dev = torch.tensor([int(s) for s in steps], dtype=torch.int64, device=device)   # one upload for the whole loop
         try:
-            for t, t_next in zip(reversed(steps), reversed(steps_next)):
+            for i, (t, t_next) in enumerate(zip(reversed(steps), reversed(steps_next))):
                 t_tensor = torch.full((x_shape[0],), t, device=device)
-                if hint_ok:
-                    self.model._uniform_time = t                 # every sample shares t: FiLM computed once
+                if hint_ok:                                      # every sample shares t: FiLM computed once
+                    k = len(steps) - 1 - i
+                    self.model._uniform_time = (t, t_dev[k:k + 1])
                 e_theta = self.model(x=x, time=t_tensor, condition=None)
                 e = torch.randn(*x_shape, device=device)
                 sigma = eta * torch.sqrt((1 - alpha[t_next]) / (1 - alpha[t])) * torch.sqrt(1 - alpha[t] / alpha[t_next])

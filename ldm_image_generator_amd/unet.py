@@ -32,7 +32,8 @@ class TimeContext:
 
     def __init__(self, time, batch, device, uniform=None):
         if uniform is not None:
-            self.t_unique = torch.tensor([int(uniform)], dtype=torch.int64, device=device)
+            # (value, 1-element int64 device tensor): no host->device copy (= stream sync) inside the denoise loop
+            self.t_unique = uniform[1] if isinstance(uniform, tuple) else torch.tensor([int(uniform)], dtype=torch.int64, device=device)
             self.slot = None
         else:
             tc = time.detach().to("cpu", torch.int64)             # one host sync per forward
