@@ -141,7 +141,7 @@ def main():
             line["roofline"]["traffic"] = tj["gemm_hbm_bytes_per_launch"]
             line["roofline"]["traffic_unit"] = "bytes per GEMM launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.md)"
             line["roofline"]["algorithmic_bytes_per_launch"] = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64))
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -158,17 +158,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x16 (&acc)[GATE
         const float *abase = p.addend ? p.addend + (long long)row0 * p.ldadd : nullptr;
         const bool late_add = !use_pre && p.addend != nullptr;
         if (m0 + WM * TM * 32 <= p.M) {                      // whole tile inside M: no per-element predicate
+            // running pointers (one 64-bit add of the uniform row stride per row) instead of 32 distinct
+            // "row offset x stride" products, which cost an SGPR each and spill
+            float *orow = obase;
+            const float *arow = abase;
 #pragma unroll
             for (int im = 0; im < TM; ++im)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int roff = im * 32 + (e & 3) + 8 * (e >> 2);
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn) {
                         float v = value(im, jn, e);
-                        if (late_add) v += abase[roff * lda_ + c.ocol[jn]];
-                        obase[roff * ldo_ + c.ocol[jn]] = v;
+                        if (late_add) v += arow[c.ocol[jn]];
+                        orow[c.ocol[jn]] = v;
                     }
+                    // rows advance 0,1,2,3, 8,9,10,11, 16,... : +1 inside a group of four, +5 to the next group
+                    const int step = ((e & 3) == 3) ? ((e == 15) ? 5 : 5) : 1;
+                    orow += (long long)step * ldo_;
+                    if (late_add) arow += (long long)step * lda_;
                 }
         } else {
 #pragma unroll
