@@ -200,8 +200,6 @@ int dispatch(const GemmP &p, int groups, hipStream_t st)
         return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch<1, 4, 1, 1, GATE, AMODE>(p, groups, st);
-    static const char *force = getenv("LDM_GEMM_TILE");          // experiment knob: "128x64"
-    if (force && force[4] == '6' && unit % 64 == 0) return launch<2, 2, 2, 1, GATE, AMODE>(p, groups, st);
     if (unit % 128 == 0) return launch<2, 2, 2, 2, GATE, AMODE>(p, groups, st);
     if (unit % 64 == 0) return launch<2, 2, 2, 1, GATE, AMODE>(p, groups, st);
     return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);

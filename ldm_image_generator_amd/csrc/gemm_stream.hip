@@ -282,8 +282,6 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
     const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
     if (gate) {
         if (amode != LDM_A_ROWS) return 0;
-        static const char *gt = getenv("LDM_GEMM_GATE_TILE");      // experiment knob: "64" -> 64x64 gated tile
-        if (gt && gt[0] == '6' && unit % 64 == 0) return launch_stream<2, 2, 1, 1, true, LDM_A_ROWS>(p, groups, st);
         if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS>(p, groups, st);
         return launch_stream<4, 1, 1, 1, true, LDM_A_ROWS>(p, groups, st);
     }
@@ -294,8 +292,6 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
         return launch_stream<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch_stream<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
-    static const char *pt = getenv("LDM_GEMM_PLAIN_TILE");         // experiment knob: "64" -> 64x64 tile
-    if (pt && pt[0] == '6' && unit % 64 == 0) return launch_stream<2, 2, 1, 1, false, LDM_A_ROWS>(p, groups, st);
     if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
     return launch_stream<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
 }
