@@ -188,6 +188,8 @@ int ldm_gate_bwd_f32(const float *dh, const float *a, const float *b, float *da,
 int ldm_relu_bwd_f32(const float *dy, const float *y, float *dx, long long n, void *stream);
 int ldm_add_f32(float *y, const float *x, long long n, void *stream);                                 /* y += x */
 int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulate, void *stream);     /* bias grads */
+/* out[Cc, R] = x[R, Cc]^T and csum[c] = sum_r x[r][c] in one pass (activation transpose + bias gradient) */
+int ldm_transpose_colsum_f32(const float *x, float *out, float *csum, long long R, int Cc, void *stream);
 int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream);        /* split-K sum */
 /* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) += per (slot, pixel) (atomic) */
 int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, const int *slot, const float *dxf, const float *dres,

@@ -312,6 +312,39 @@ __global__ void l1_loss_bwd_kernel(const float *__restrict__ p, const float *__r
     grad[i] = sgn * gscale[0] * inv_n;
 }
 
+// [R, Cc] -> [Cc, R] and, in the same pass, csum[c] += sum_r x[r][c] (the bias gradient that always accompanies a
+// weight-gradient GEMM over the transposed activation): 32x32 LDS tiles, one atomic per column per tile
+__global__ __launch_bounds__(256) void transpose_colsum_kernel(const float *__restrict__ x, float *__restrict__ out, float *__restrict__ csum,
+                                                               long long R, int Cc)
+{
+    __shared__ float tile[32][33];
+    __shared__ float part[8][32];
+    const long long r0 = (long long)blockIdx.y * 32;
+    const int c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float s = 0.f;
+    for (int i = ty; i < 32; i += 8) {
+        const long long rr = r0 + i;
+        const int cc = c0 + tx;
+        const float v = (rr < R && cc < Cc) ? x[rr * Cc + cc] : 0.f;
+        tile[i][tx] = v;
+        s += v;
+    }
+    part[ty][tx] = s;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int cc = c0 + i;
+        const long long rr = r0 + tx;
+        if (rr < R && cc < Cc) out[(long long)cc * R + rr] = tile[tx][i];
+    }
+    if (ty == 0 && c0 + tx < Cc) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][tx];
+        atomicAdd(csum + c0 + tx, t);
+    }
+}
+
 // ---- grouped-conv weight gradient helper: transposed im2col -----------------------------------------
 // out[g][tap*32 + ci][m] = x[(pixel m shifted by tap)][g*32 + ci]  (0 outside the image);  x is [B,H,W,C]
 __global__ __launch_bounds__(256) void im2col3x3_t_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int H, int W, int C)
@@ -367,15 +400,17 @@ __device__ __forceinline__ bool tok_src(const AttnB &p, int wr, int wc, int j, i
 }
 
 // One wave per (sample, window, head), lane i = token i (query AND key role).  LDS per wave:
-// K, V, Qs (scaled q), dO : [L][32] each;  P, dS : [L][L+1] each.
+// region A [2][L][32]: K, V during phase 1, then overwritten by Qs (scaled q), dO for phase 2;
+// region B [2][L][L+1]: P, dS.  20 KB per wave -> 8 waves per CU.
 template <int LMAX>
 __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROW = LMAX * 32, MAT = LMAX * (LMAX + 1);
+    constexpr int RS = 36;                         // row stride of the [L][32] images: 16-B aligned, conflict-free b128 row writes
+    constexpr int ROW = LMAX * RS, MAT = LMAX * (LMAX + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *Ks = smem + wave * (4 * ROW + 2 * MAT + LMAX);
-    float *Vs = Ks + ROW, *Qs = Vs + ROW, *dOs = Qs + ROW, *Ps = dOs + ROW, *dSs = Ps + MAT, *Kb = dSs + MAT;
+    float *Ks = smem + wave * (2 * ROW + 2 * MAT + LMAX + 4);
+    float *Vs = Ks + ROW, *Qs = Ks, *dOs = Vs, *Ps = Vs + ROW, *dSs = Ps + MAT, *Kb = dSs + MAT;
     const int L = p.L, C = p.C;
     const long long gw = (long long)blockIdx.x * 2 + wave;
     const bool active = gw < p.total_waves;
@@ -390,36 +425,30 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
 
     int sy = 0, sx = 0, py = 0, px = 0;
     bool ok = false;
-    float qr[32], gr[32];                      // this lane's scaled query and output gradient (registers: no LDS row conflicts)
+    f32x4 qr[8], gr[8];                            // this lane's scaled query and output gradient
 #pragma unroll
-    for (int d = 0; d < 32; ++d) qr[d] = gr[d] = 0.f;
+    for (int c = 0; c < 8; ++c) qr[c] = gr[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (active && lane < L) {
         ok = tok_src(p, wr, wc, lane, sy, sx, py, px);
         const long long tokrow = img + (long long)sy * p.W + sx;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            f32x4 qv, kv, vv, gv;
+            f32x4 qv, kv, vv;
             if (ok) {
                 const float *row = p.qkv + tokrow * 3 * C + head * 32 + 4 * c;
                 qv = *(const f32x4 *)row;
                 kv = *(const f32x4 *)(row + C);
                 vv = *(const f32x4 *)(row + 2 * C);
-                gv = *(const f32x4 *)(p.dctx + tokrow * C + head * 32 + 4 * c);
-            } else {
+                gr[c] = *(const f32x4 *)(p.dctx + tokrow * C + head * 32 + 4 * c);
+            } else {                              // zero-padded token (projection of 0 = bias); its output is cropped: dO = 0
                 qv = *(const f32x4 *)(p.bias + head * 32 + 4 * c);
                 kv = *(const f32x4 *)(p.bias + C + head * 32 + 4 * c);
                 vv = *(const f32x4 *)(p.bias + 2 * C + head * 32 + 4 * c);
-                gv = f32x4{0.f, 0.f, 0.f, 0.f};                       // cropped output: no gradient
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Ks[lane * 32 + 4 * c + e] = kv[e];
-                Vs[lane * 32 + 4 * c + e] = vv[e];
-                qr[4 * c + e] = qv[e] * scale;
-                gr[4 * c + e] = gv[e];
-                Qs[lane * 32 + 4 * c + e] = qr[4 * c + e];
-                dOs[lane * 32 + 4 * c + e] = gv[e];
-            }
+            for (int e = 0; e < 4; ++e) qr[c][e] = qv[e] * scale;
+            *(f32x4 *)(Ks + lane * RS + 4 * c) = kv;
+            *(f32x4 *)(Vs + lane * RS + 4 * c) = vv;
         }
         float kb = 0.f;
         if (!p.global) {
@@ -437,16 +466,24 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
     __syncthreads();
     // ---- phase 1 (lane = query i): P[i][:], dS[i][:], dq_i ----------------------------------------
     if (active && lane < L) {
-        float s[LMAX];
+        float s[LMAX], dp[LMAX];
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < LMAX; ++j)
             if (j < L) {
-                float a = 0.f;
+                float a = 0.f, g = 0.f;
 #pragma unroll
-                for (int d = 0; d < 32; ++d) a = fmaf(qr[d], Ks[j * 32 + d], a);
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 kv = *(const f32x4 *)(Ks + j * RS + 4 * c), vv = *(const f32x4 *)(Vs + j * RS + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a = fmaf(qr[c][e], kv[e], a);
+                        g = fmaf(gr[c][e], vv[e], g);
+                    }
+                }
                 a += Kb[j];
                 s[j] = a;
+                dp[j] = g;
                 mx = fmaxf(mx, a);
             }
         float sum = 0.f;
@@ -457,20 +494,15 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
                 sum += s[j];
             }
         float dot = 0.f;
-        float dp[LMAX];
 #pragma unroll
         for (int j = 0; j < LMAX; ++j)
             if (j < L) {
                 s[j] = s[j] / sum;
-                float a = 0.f;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) a = fmaf(gr[d], Vs[j * 32 + d], a);
-                dp[j] = a;
-                dot = fmaf(s[j], a, dot);
+                dot = fmaf(s[j], dp[j], dot);
             }
-        float dq[32];
+        f32x4 dq[8];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+        for (int c = 0; c < 8; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < LMAX; ++j)
             if (j < L) {
@@ -478,42 +510,60 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
                 Ps[lane * (LMAX + 1) + j] = s[j];
                 dSs[lane * (LMAX + 1) + j] = ds;
 #pragma unroll
-                for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, Ks[j * 32 + d], dq[d]);
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 kv = *(const f32x4 *)(Ks + j * RS + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq[c][e] = fmaf(ds, kv[e], dq[c][e]);
+                }
             }
         if (ok) {
             float *o = p.dqkv + (img + (long long)sy * p.W + sx) * 3 * C + head * 32;
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                *(f32x4 *)(o + 4 * c) = f32x4{dq[4 * c] * scale, dq[4 * c + 1] * scale, dq[4 * c + 2] * scale, dq[4 * c + 3] * scale};
+                *(f32x4 *)(o + 4 * c) = f32x4{dq[c][0] * scale, dq[c][1] * scale, dq[c][2] * scale, dq[c][3] * scale};
+        }
+    }
+    __syncthreads();
+    if (active && lane < L) {                     // K, V are no longer needed: region A now holds Qs, dO
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            *(f32x4 *)(Qs + lane * RS + 4 * c) = qr[c];
+            *(f32x4 *)(dOs + lane * RS + 4 * c) = gr[c];
         }
     }
     __syncthreads();
     // ---- phase 2 (lane = key j): dk_j = sum_i dS[i][j] qs_i ; dv_j = sum_i P[i][j] dO_i ----------------
     if (active && lane < L) {
-        float dk[32], dv[32];
+        f32x4 dk[8], dv[8];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) dk[d] = dv[d] = 0.f;
+        for (int c = 0; c < 8; ++c) dk[c] = dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < L; ++i) {
             const float ds = dSs[i * (LMAX + 1) + lane], pp = Ps[i * (LMAX + 1) + lane];
 #pragma unroll
-            for (int d = 0; d < 32; ++d) {
-                dk[d] = fmaf(ds, Qs[i * 32 + d], dk[d]);
-                dv[d] = fmaf(pp, dOs[i * 32 + d], dv[d]);
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 qv = *(const f32x4 *)(Qs + i * RS + 4 * c), gv = *(const f32x4 *)(dOs + i * RS + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dk[c][e] = fmaf(ds, qv[e], dk[c][e]);
+                    dv[c][e] = fmaf(pp, gv[e], dv[c][e]);
+                }
             }
         }
         if (ok) {
             float *o = p.dqkv + (img + (long long)sy * p.W + sx) * 3 * C + head * 32;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                *(f32x4 *)(o + C + 4 * c) = f32x4{dk[4 * c], dk[4 * c + 1], dk[4 * c + 2], dk[4 * c + 3]};
-                *(f32x4 *)(o + 2 * C + 4 * c) = f32x4{dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]};
+                *(f32x4 *)(o + C + 4 * c) = dk[c];
+                *(f32x4 *)(o + 2 * C + 4 * c) = dv[c];
             }
         } else {                                  // zero-padded token: k, v are the in-proj bias
 #pragma unroll
-            for (int d = 0; d < 32; ++d) {
-                atomicAdd(p.dbias_pad + C + head * 32 + d, dk[d]);
-                atomicAdd(p.dbias_pad + 2 * C + head * 32 + d, dv[d]);
-            }
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(p.dbias_pad + C + head * 32 + 4 * c + e, dk[c][e]);
+                    atomicAdd(p.dbias_pad + 2 * C + head * 32 + 4 * c + e, dv[c][e]);
+                }
         }
     }
 }
@@ -561,6 +611,17 @@ extern "C" int ldm_colsum_f32(const float *x, float *out, long long M, int N, in
     const int slab = 512;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, blocks_for(M, slab)), dim3(256), 0, st, x, out, M, N, slab);
     LDM_CHECK_LAUNCH("ldm_colsum_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_transpose_colsum_f32(const float *x, float *out, float *csum, long long R, int Cc, void *stream)
+{
+    LDM_REQUIRE(x && out && csum && R > 0 && Cc > 0, "ldm_transpose_colsum_f32: bad arguments");
+    LDM_REQUIRE((R + 31) / 32 <= 0x7fffffffLL, "ldm_transpose_colsum_f32: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(csum, 0, (size_t)Cc * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_transpose_colsum_f32: memset failed"); return LDM_ELAUNCH; }
+    hipLaunchKernelGGL(transpose_colsum_kernel, dim3((Cc + 31) / 32, (unsigned)((R + 31) / 32)), dim3(256), 0, st, x, out, csum, R, Cc);
+    LDM_CHECK_LAUNCH("ldm_transpose_colsum_f32");
     return LDM_OK;
 }
 
@@ -685,7 +746,7 @@ extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_pr
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dbias_pad, 0, (size_t)3 * C * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_window_attention_bwd_f32: memset failed"); return LDM_ELAUNCH; }
     constexpr int LMAX = 36;
-    const size_t smem = 2ull * (4 * LMAX * 32 + 2 * LMAX * (LMAX + 1) + LMAX) * sizeof(float);
+    const size_t smem = 2ull * (2 * LMAX * 36 + 2 * LMAX * (LMAX + 1) + LMAX + 4) * sizeof(float);
     hipLaunchKernelGGL(window_attention_bwd_kernel<LMAX>, dim3((unsigned)((p.total_waves + 1) / 2)), dim3(128), smem, st, p);
     LDM_CHECK_LAUNCH("ldm_window_attention_bwd_f32");
     return LDM_OK;

@@ -14,7 +14,7 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
                    GemmDesc)
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
-           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "reduce_partials", "channelnorm_film_bwd",
+           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
            "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
@@ -228,6 +228,11 @@ def colsum(x, M, N, out=None, accumulate=False):
         out = torch.empty(N, device=x.device, dtype=torch.float32)
     _call("ldm_colsum_f32", _dev(x, "x"), _dev(out, "out"), M, N, int(accumulate))
     return out
+
+
+def transpose_colsum(x, out, csum):
+    r, c = x.shape
+    _call("ldm_transpose_colsum_f32", _dev(x, "x"), _dev(out, "out"), _dev(csum, "csum"), r, c)
 
 
 def reduce_partials(parts, S, n, out):

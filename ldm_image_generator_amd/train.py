@@ -25,6 +25,16 @@ def _T(x, rows=None):
     return out
 
 
+def _T_colsum(x):
+    """[M, C] -> ([C, M], column sums [C]) in one pass: the transposed activation for the weight-gradient GEMM and
+    the bias gradient that goes with it."""
+    m, c = x.shape
+    out = torch.empty(c, m, device=x.device, dtype=torch.float32)
+    csum = torch.empty(c, device=x.device, dtype=torch.float32)
+    ops.transpose_colsum(x, out, csum)
+    return out, csum
+
+
 class _WeightT:
     """W [N, K] -> W^T [K, N], cached per parameter version."""
 
@@ -132,9 +142,8 @@ def block_backward(sv, dy, ctx, grads):
     dev = x.device
     regs = sv["regs"]
     f = regs[0].a.weight.shape[0]
-    dy_t = _T(dy)
+    dy_t, bias_dy = _T_colsum(dy)
     xf_t = _T(xf)
-    bias_dy = ops.colsum(dy, m, c)
     # ---- RandomMoE: y += sum_e c_e(a_e(xf) * relu(b_e(xf))) ----------------------------------------------
     dwc = grad_weight(dy_t, _T(sv["hid"]), m)                       # [C, 3F]
     dhid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
@@ -145,9 +154,10 @@ def block_backward(sv, dy, ctx, grads):
     dxf = torch.empty(m, c, device=dev, dtype=torch.float32)
     ops.gemm(da, m, c, 3 * f, [WT.get(_w2d(r.a.weight), r.a.weight) for r in regs], dxf, seg_mode=ops.SEG_K)
     ops.gemm(db, m, c, 3 * f, [WT.get(_w2d(r.b.weight), r.b.weight) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)
-    dwa = grad_weight(_T(da), xf_t, m)                              # [3F, C]
-    dwb = grad_weight(_T(db), xf_t, m)
-    dba, dbb = ops.colsum(da, m, 3 * f), ops.colsum(db, m, 3 * f)
+    da_t, dba = _T_colsum(da)
+    db_t, dbb = _T_colsum(db)
+    dwa = grad_weight(da_t, xf_t, m)                                # [3F, C]
+    dwb = grad_weight(db_t, xf_t, m)
     for e, r in enumerate(regs):
         grads.add(r.c.weight, dwc[:, e * f:(e + 1) * f])
         grads.add(r.c.bias, bias_dy.clone())
@@ -167,8 +177,9 @@ def block_backward(sv, dy, ctx, grads):
         ops.window_attention_bwd(sv["qkv"], att.in_proj_bias.detach(), xf, dctx, dqkv, dpad, b, h, w, c,
                                  blk.self_attention.window_size, blk.self_attention.shift)
         ops.gemm(dqkv, m, c, 3 * c, [WT.get(att.in_proj_weight.detach(), att.in_proj_weight)], dxf, addend=dxf)
-        grads.add(att.in_proj_weight, grad_weight(_T(dqkv), xf_t, m))
-        grads.add(att.in_proj_bias, ops.add_(ops.colsum(dqkv, m, 3 * c), dpad))
+        dqkv_t, dbin = _T_colsum(dqkv)
+        grads.add(att.in_proj_weight, grad_weight(dqkv_t, xf_t, m))
+        grads.add(att.in_proj_bias, ops.add_(dbin, dpad))
     # ---- grouped 3x3 conv ------------------------------------------------------------------------------
     g = c // 32
     wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
@@ -211,13 +222,15 @@ def encodings_backward(enc, codes, hid, dfilm, grads):
             out[:m] = t
             return out
         codes, hid, dfilm = pad(codes), pad(hid), pad(dfilm)
-    grads.add(enc.proj2.weight, grad_weight(_T(dfilm), _T(hid), mp))
-    grads.add(enc.proj2.bias, ops.colsum(dfilm, mp, 2 * c))
+    dfilm_t, db2 = _T_colsum(dfilm)
+    grads.add(enc.proj2.weight, grad_weight(dfilm_t, _T(hid), mp))
+    grads.add(enc.proj2.bias, db2)
     dh = torch.empty(mp, 4 * c, device=codes.device, dtype=torch.float32)
     ops.gemm(dfilm, mp, 4 * c, 2 * c, [WT.get(_w2d(enc.proj2.weight), enc.proj2.weight)], dh)
     ops.relu_bwd(dh, hid, dh)
-    grads.add(enc.proj1.weight, grad_weight(_T(dh), _T(codes), mp))
-    grads.add(enc.proj1.bias, ops.colsum(dh, mp, 4 * c))
+    dh_t, db1 = _T_colsum(dh)
+    grads.add(enc.proj1.weight, grad_weight(dh_t, _T(codes), mp))
+    grads.add(enc.proj1.bias, db1)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -307,15 +320,17 @@ class UNetFunction(torch.autograd.Function):
                 dlo = torch.empty(bb * lh * lw, cn, device=dev, dtype=torch.float32)
                 ops.sumpool2(drows, dlo, bb, 2 * lh, 2 * lw, cn)
                 mlo = bb * lh * lw
-                grads.add(conv.weight, grad_weight(_T(dlo), _T(lo), mlo))
-                grads.add(conv.bias, ops.colsum(dlo, mlo, cn))
+                dlo_t, dbl2 = _T_colsum(dlo)
+                grads.add(conv.weight, grad_weight(dlo_t, _T(lo), mlo))
+                grads.add(conv.bias, dbl2)
                 drows = torch.empty(mlo, lo.shape[1], device=dev, dtype=torch.float32)
                 ops.gemm(dlo, mlo, lo.shape[1], cn, [WT.get(_w2d(conv.weight), conv.weight)], drows)
             elif kind == "down":
                 conv, pooled, (bb, lh, lw) = sv["conv"], sv["pooled"], sv["shape"]
                 mlo = bb * lh * lw
-                grads.add(conv.weight, grad_weight(_T(drows), _T(pooled), mlo))
-                grads.add(conv.bias, ops.colsum(drows, mlo, conv.weight.shape[0]))
+                dr_t, dbd = _T_colsum(drows)
+                grads.add(conv.weight, grad_weight(dr_t, _T(pooled), mlo))
+                grads.add(conv.bias, dbd)
                 dpool = torch.empty(mlo, pooled.shape[1], device=dev, dtype=torch.float32)
                 ops.gemm(drows, mlo, pooled.shape[1], conv.weight.shape[0], [WT.get(_w2d(conv.weight), conv.weight)], dpool)
                 hi = dskip.pop(sv["level"]).clone()                         # start from the skip gradient, add the pooled path
