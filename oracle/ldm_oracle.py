@@ -294,7 +294,7 @@ def ddim_coefficients(alpha_cum, t, t_next, eta=0.0):
 
 
 def ddim_sample(sd, x_shape, seed=None, num_steps=20, eta=0.0, training=True, x_init=None,
-                unet_kwargs=None, prefix="model.", decisions=None):
+                unet_kwargs=None, prefix="model.", decisions=None, schedule="linear", noises=None):
     """ddpm.py:51-93 on CPU (use_autocast is a no-op on CPU, ddpm.py:75)."""
     unet_kwargs = unet_kwargs or {}
     if seed is not None:                                  # :56-61
@@ -302,12 +302,18 @@ def ddim_sample(sd, x_shape, seed=None, num_steps=20, eta=0.0, training=True, x_
         torch.manual_seed(seed)
     x = torch.randn(*x_shape) if x_init is None else x_init.clone()
     _, _, alpha_cum = schedule_tables()
-    steps, steps_next = ddim_steps(num_steps)
+    if schedule == "linear":
+        steps, steps_next = ddim_steps(num_steps)
+    else:                                                 # ddpm.py:68-69: an explicit list of timesteps
+        steps = list(schedule)
+        steps_next = [0] + steps[:-1]
     with torch.no_grad():
         for t, t_next in zip(reversed(steps), reversed(steps_next)):
             tt = torch.full((x_shape[0],), t)
             e_theta = unet_forward(sd, x, tt, training=training, prefix=prefix, decisions=decisions, **unet_kwargs)
             e = torch.randn(*x_shape)                     # :80 (consumed even when sigma == 0)
+            if noises is not None:                        # tests inject the per-step noise (device RNG streams differ)
+                e = noises.pop(0)
             sigma, s1, s2, s3, s4 = ddim_coefficients(alpha_cum, t, t_next, eta)
             x_t0 = (x - s1 * e_theta) / s2
             x = x_t0 if t == 0 else s3 * x_t0 + s4 * e_theta + sigma * e

@@ -201,3 +201,67 @@ def test_encoder_tiny_and_full(gpu_device):
     full = formula(Encoder())
     with torch.no_grad():
         assert rel_l2(full(T(g["x"]).cuda()).cpu(), T(g["z"])) < 1e-5
+
+
+def test_unet_non_square_and_batch_one(gpu_device):
+    """H != W (window padding differs per axis at every level), B = 1, odd batch; vs the oracle evaluated live."""
+    from ldm_image_generator_amd import synth
+    from ldm_image_generator_amd.unet import UNet
+    cfg = dict(input_channels=8, stages=[1, 2, 2], channels=[32, 64, 64])
+    net = formula(UNet(**cfg)).eval()
+    sd = synth.fill_state_dict(net.state_dict())
+    for (b, h, w) in [(1, 16, 40), (3, 56, 24)]:
+        x = torch.randn(b, 8, h, w, generator=torch.Generator().manual_seed(h))
+        t = torch.randint(0, 1000, (b,), generator=torch.Generator().manual_seed(w))
+        with torch.no_grad():
+            random.seed(1)
+            y = net(x.cuda(), t.cuda()).cpu()
+            random.seed(1)
+            ref = O.unet_forward(sd, x, t, stages=cfg["stages"], channels=cfg["channels"], training=False)
+        assert rel_l2(y, ref) < 2e-5, (b, h, w)
+
+
+def test_sample_schedule_list_eta_and_errors(tiny_unet):
+    """ddpm.py:68-71 (explicit schedule list, unknown schedule -> TypeError) and eta > 0 (sigma * e term) with injected noise."""
+    from ldm_image_generator_amd import synth
+    from ldm_image_generator_amd.ddpm import DDPM
+    d = DDPM(model=tiny_unet)
+    tiny_unet.eval()
+    sd = synth.fill_state_dict(tiny_unet.state_dict())
+    xT = torch.randn(2, 8, 32, 32, generator=torch.Generator().manual_seed(3))
+    sched = [0, 130, 777, 999]
+    got = d.sample((2, 8, 32, 32), seed=4, schedule=sched, x_init=xT, progress=False).cpu()
+    ref = O.ddim_sample(sd, (2, 8, 32, 32), seed=4, training=False, x_init=xT, unet_kwargs=dict(stages=TINY["stages"], channels=TINY["channels"]),
+                        prefix="", schedule=sched)
+    assert rel_l2(got, ref) < 1e-4
+    with pytest.raises(TypeError):
+        d.sample((1, 8, 32, 32), schedule="cosine", progress=False)
+    # eta > 0: replay the device noise of the HIP run inside the oracle
+    torch.manual_seed(9)
+    torch.cuda.manual_seed(9)
+    random.seed(9)
+    got = d.sample((2, 8, 32, 32), seed=9, num_steps=4, eta=0.7, x_init=xT, progress=False).cpu()
+    torch.manual_seed(9)
+    torch.cuda.manual_seed(9)
+    noises = [torch.randn(2, 8, 32, 32, device="cuda").cpu() for _ in range(5)][1:]        # first draw is x_T (replaced by x_init)
+    ref = O.ddim_sample(sd, (2, 8, 32, 32), seed=9, num_steps=4, eta=0.7, training=False, x_init=xT,
+                        unet_kwargs=dict(stages=TINY["stages"], channels=TINY["channels"]), prefix="", noises=noises)
+    assert rel_l2(got, ref) < 1e-4
+
+
+def test_custom_loss_function_and_vae_wrapper(gpu_device):
+    """DDPM(loss_function=...) other than L1 keeps working through autograd; VAE.encode/decode wrappers (vae.py:45-52)."""
+    from ldm_image_generator_amd.ddpm import DDPM
+    from ldm_image_generator_amd.unet import UNet
+    from ldm_image_generator_amd.vae import VAE, Decoder, Encoder
+    net = formula(UNet(input_channels=8, stages=[1, 1], channels=[32, 64])).train()
+    d = DDPM(model=net, loss_function=torch.nn.MSELoss())
+    random.seed(0)
+    torch.manual_seed(0)
+    loss = d.calculate_loss(torch.randn(4, 8, 16, 16, device="cuda"))
+    loss.backward()
+    assert torch.isfinite(loss) and net.encoder_first.weight.grad is not None
+    vae = VAE(formula(Encoder(channels=[32, 32], stages=[1, 1])), formula(Decoder(channels=[32, 32], stages=[1, 1])), None)
+    img = torch.randn(2, 3, 16, 16, device="cuda")
+    z = vae.encode(img)
+    assert z.shape == (2, 8, 8, 8) and vae.decode(z).shape == (2, 3, 16, 16)
