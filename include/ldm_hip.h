@@ -32,6 +32,7 @@ extern "C" {
 
 #define LDM_MAX_SEG     4
 #define LDM_MAX_TABLE   32
+#define LDM_MAX_LEVELS  8
 
 /* epilogue activation of ldm_gemm_f32 */
 #define LDM_ACT_NONE    0
@@ -177,6 +178,38 @@ int ldm_nhwc_to_nchw_f32(const float *x, float *out, int B, int C, int HW, void 
 
 /* sample_ldm.py:75-77: clamp(-1,1) -> *127.5+127.5 -> uint8 truncation, NCHW -> NHWC bytes. */
 int ldm_to_uint8_hwc(const float *img, unsigned char *out, int B, int C, int HW, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native executor of one UNet forward (unet.py:89-103): the per-step body of the denoise loop as ONE call.
+ * The plan is a caller-owned description (device pointers to the reference's parameters in their
+ * state_dict layout, plus the re-laid-out grouped-conv weight); nothing is copied or retained.
+ * decisions[k] for block k in execution order (encoder stages, then decoder stages): -1 = skipped by
+ * stochastic depth (unet.py:39), else e1 * 4 + e2 with the two expert indices drawn by
+ * random.sample (modules.py:35).  Results are bit-identical to issuing the same launches one by one.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ldm_unet_block {
+    int attention, shift;                    /* window attention present / its shift (unet.py:55-57)       */
+    const float *conv_w, *conv_b;            /* grouped 3x3, packed [C][tap][32]; bias [C]                */
+    const float *enc_w1, *enc_b1, *enc_w2, *enc_b2;          /* Encodings.proj1 [4C,2C], proj2 [2C,4C]      */
+    const float *a_w[5], *a_b[5], *b_w[5], *b_b[5], *c_w[5], *c_b[5];   /* ReGLUs: [0] general, [1..4] experts */
+    const float *in_w, *in_b, *out_w, *out_b;                /* MultiheadAttention in_proj / out_proj        */
+} ldm_unet_block;
+
+typedef struct ldm_unet_plan {
+    int levels, input_channels, window, nblocks;
+    float eps;
+    int channels[LDM_MAX_LEVELS], enc_blocks[LDM_MAX_LEVELS], dec_blocks[LDM_MAX_LEVELS];
+    const float *stem_w, *stem_b, *head_w, *head_b;          /* encoder_first [C0,Cin]; decoder_last [C0,Cin] */
+    const float *down_w[LDM_MAX_LEVELS], *down_b[LDM_MAX_LEVELS];   /* encoder ch_conv of level i -> i+1     */
+    const float *up_w[LDM_MAX_LEVELS], *up_b[LDM_MAX_LEVELS];       /* decoder ch_conv of level i+1 -> i     */
+    const float *pos_freq[LDM_MAX_LEVELS], *time_freq[LDM_MAX_LEVELS];
+    const ldm_unet_block *blocks;            /* HOST array, execution order                                   */
+} ldm_unet_plan;
+
+size_t ldm_unet_workspace_bytes(const ldm_unet_plan *plan, int B, int H, int W, int nT);
+int ldm_unet_forward_f32(const ldm_unet_plan *plan, const float *x_nchw, const long long *t_unique, int nT, const int *slot,
+                         const int *decisions /* host */, int B, int H, int W, void *workspace, size_t ws_bytes,
+                         float *out_nchw, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step (ddpm.py:39-48 + autograd of unet.py / modules.py / attention.py).  GEMM-shaped

@@ -47,6 +47,31 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+LDM_MAX_LEVELS = 8
+
+
+class UNetBlockDesc(ctypes.Structure):
+    """struct ldm_unet_block"""
+    _fields_ = [("attention", ctypes.c_int), ("shift", ctypes.c_int),
+                ("conv_w", c_fp), ("conv_b", c_fp),
+                ("enc_w1", c_fp), ("enc_b1", c_fp), ("enc_w2", c_fp), ("enc_b2", c_fp),
+                ("a_w", c_fp * 5), ("a_b", c_fp * 5), ("b_w", c_fp * 5), ("b_b", c_fp * 5), ("c_w", c_fp * 5), ("c_b", c_fp * 5),
+                ("in_w", c_fp), ("in_b", c_fp), ("out_w", c_fp), ("out_b", c_fp)]
+
+
+class UNetPlanDesc(ctypes.Structure):
+    """struct ldm_unet_plan"""
+    _fields_ = [("levels", ctypes.c_int), ("input_channels", ctypes.c_int), ("window", ctypes.c_int), ("nblocks", ctypes.c_int),
+                ("eps", ctypes.c_float),
+                ("channels", ctypes.c_int * LDM_MAX_LEVELS), ("enc_blocks", ctypes.c_int * LDM_MAX_LEVELS),
+                ("dec_blocks", ctypes.c_int * LDM_MAX_LEVELS),
+                ("stem_w", c_fp), ("stem_b", c_fp), ("head_w", c_fp), ("head_b", c_fp),
+                ("down_w", c_fp * LDM_MAX_LEVELS), ("down_b", c_fp * LDM_MAX_LEVELS),
+                ("up_w", c_fp * LDM_MAX_LEVELS), ("up_b", c_fp * LDM_MAX_LEVELS),
+                ("pos_freq", c_fp * LDM_MAX_LEVELS), ("time_freq", c_fp * LDM_MAX_LEVELS),
+                ("blocks", ctypes.POINTER(UNetBlockDesc))]
+
+
 _I, _L, _F, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
 
 # name -> (restype, argtypes); every symbol declared in include/ldm_hip.h
@@ -56,6 +81,9 @@ SIGNATURES = {
     "ldm_device_ok": (_I, []),
     "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "ldm_gemm_variant": (_I, [_I]),
+    "ldm_unet_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(UNetPlanDesc), _I, _I, _I, _I]),
+    "ldm_unet_forward_f32": (_I, [ctypes.POINTER(UNetPlanDesc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I, _P,
+                                  ctypes.c_size_t, _P, _P]),
     "ldm_prof_enable": (_I, [_I]),
     "ldm_prof_read": (_I, [ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ldm_channelnorm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),

@@ -195,6 +195,9 @@ class UNet(nn.Module):
         self.channels = list(channels)
         self._uniform_time = None          # set by DDPM.sample: every sample shares this timestep
         self._tables = {}
+        self._plan = None                  # (key, ctypes plan, keep-alive list) for the native executor
+        self._workspace = None
+        self.native_forward = True         # inference forwards run through ldm_unet_forward_f32 (one C call per forward)
 
     def _level_blocks(self, i):
         n = len(self.encoder_stages)
@@ -232,6 +235,96 @@ class UNet(nn.Module):
                 films[blk] = film[k]
         return films
 
+    def _native_plan(self, dev):
+        """struct ldm_unet_plan over the live parameters (rebuilt when any of them moved / changed version)."""
+        import ctypes
+        from ._lib import UNetBlockDesc, UNetPlanDesc
+        # The plan holds POINTERS to the live parameters, so in-place updates (optimizer steps, load_state_dict)
+        # need no rebuild; only the re-laid-out grouped-conv weights are copies (checked by version here), and
+        # device / dtype moves drop the plan in _apply().
+        order = self._plan[3] if self._plan is not None else \
+            [blk for l in self.encoder_stages for blk in l.stage.blocks] + [blk for l in self.decoder_stages for blk in l.stage.blocks]
+        key = (str(dev), tuple((blk.conv.weight.data_ptr(), blk.conv.weight._version) for blk in order))
+        if self._plan is not None and self._plan[0] == key:
+            return self._plan[1]
+        keep = []
+
+        def ptr(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        blocks = (UNetBlockDesc * len(order))()
+        for bd, blk in zip(blocks, order):
+            bd.attention = int(blk.attention_flag)
+            bd.shift = blk.self_attention.shift if blk.attention_flag else 0
+            bd.conv_w, bd.conv_b = ptr(blk._conv_weight()), ptr(blk.conv.bias)
+            enc = blk.encodings
+            bd.enc_w1, bd.enc_b1, bd.enc_w2, bd.enc_b2 = ptr(enc.proj1.weight), ptr(enc.proj1.bias), ptr(enc.proj2.weight), ptr(enc.proj2.bias)
+            for k, r in enumerate([blk.ffn.general] + list(blk.ffn.experts)):
+                bd.a_w[k], bd.a_b[k] = ptr(r.a.weight), ptr(r.a.bias)
+                bd.b_w[k], bd.b_b[k] = ptr(r.b.weight), ptr(r.b.bias)
+                bd.c_w[k], bd.c_b[k] = ptr(r.c.weight), ptr(r.c.bias)
+            if blk.attention_flag:
+                att = blk.self_attention.attention
+                bd.in_w, bd.in_b = ptr(att.in_proj_weight), ptr(att.in_proj_bias)
+                bd.out_w, bd.out_b = ptr(att.out_proj.weight), ptr(att.out_proj.bias)
+        plan = UNetPlanDesc()
+        n = len(self.encoder_stages)
+        plan.levels, plan.input_channels, plan.window, plan.nblocks = n, self.input_channels, 6, len(order)
+        plan.eps = order[0].norm.eps
+        for i in range(n):
+            plan.channels[i] = self.channels[i]
+            plan.enc_blocks[i] = len(self.encoder_stages[i].stage.blocks)
+            plan.dec_blocks[i] = len(self.decoder_stages[n - 1 - i].stage.blocks)
+            pf, tf = sinusoidal.FREQS.get(self.channels[i], dev)
+            plan.pos_freq[i], plan.time_freq[i] = ptr(pf), ptr(tf)
+            if i < n - 1:
+                down = self.encoder_stages[i].ch_conv[0]
+                up = self.decoder_stages[n - 1 - i].ch_conv[1]
+                plan.down_w[i], plan.down_b[i] = ptr(down.weight), ptr(down.bias)
+                plan.up_w[i], plan.up_b[i] = ptr(up.weight), ptr(up.bias)
+        plan.stem_w, plan.stem_b = ptr(self.encoder_first.weight), ptr(self.encoder_first.bias)
+        plan.head_w, plan.head_b = ptr(self.decoder_last.weight), ptr(self.decoder_last.bias)
+        plan.blocks = ctypes.cast(blocks, ctypes.POINTER(UNetBlockDesc))
+        keep.append(blocks)
+        self._plan = (key, plan, keep, order)
+        return plan
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plan = None                  # parameters are about to be replaced (.to / .cuda / .float)
+        self._tables = {}
+        return super()._apply(fn, *args, **kwargs)
+
+    def _forward_native(self, x, ctx):
+        """The whole forward as one C call (csrc/unet_exec.cpp): same launches, same order, same bits."""
+        import ctypes
+        from . import _lib
+        b, cin, h, w = x.shape
+        dev = x.device
+        plan = self._native_plan(dev)
+        order = self._plan[3]
+        dec = (ctypes.c_int * len(order))()
+        for k, blk in enumerate(order):                          # Python-RNG draws, reference order
+            d = blk.draw()
+            dec[k] = -1 if d is None else d[0] * 4 + d[1]
+        lib = _lib.load()
+        nt = ctx.t_unique.numel()
+        need = lib.ldm_unet_workspace_bytes(ctypes.byref(plan), b, h, w, nt)
+        if need == 0:
+            raise ValueError("UNet: input %dx%d is not divisible by 2**%d" % (h, w, len(self.channels) - 1))
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
+        x = x.contiguous().float()
+        _lib.check(lib.ldm_unet_forward_f32(ctypes.byref(plan), x.data_ptr(), ctx.t_unique.data_ptr(), nt,
+                                            None if ctx.slot is None else ctx.slot.data_ptr(), dec, b, h, w,
+                                            self._workspace.data_ptr(), need, out.data_ptr(),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_unet_forward_f32")
+        return out
+
     def forward(self, x, time, condition=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training step: same kernels + saved activations, hand-written backward (train.py)
@@ -240,7 +333,12 @@ class UNet(nn.Module):
             return UNetFunction.apply(self, x, time, *params)
         b, cin, h, w = x.shape
         dev = x.device
+        if not x.is_cuda:
+            from ._lib import LdmHipUnavailable
+            raise LdmHipUnavailable("x must be a GPU tensor: the HIP path is the only implementation (no CPU fallback)")
         ctx = TimeContext(time, b, dev, uniform=self._uniform_time)
+        if self.native_forward:
+            return self._forward_native(x, ctx)
         # Python-RNG decisions of all 36 blocks in execution order (identical draw order to the
         # reference, which draws them lazily inside each block: nothing else touches `random`).
         order = [blk for l in self.encoder_stages for blk in l.stage.blocks] + \

@@ -265,3 +265,34 @@ def test_custom_loss_function_and_vae_wrapper(gpu_device):
     img = torch.randn(2, 3, 16, 16, device="cuda")
     z = vae.encode(img)
     assert z.shape == (2, 8, 8, 8) and vae.decode(z).shape == (2, 3, 16, 16)
+
+
+def test_native_forward_is_bit_identical_to_python_orchestration(tiny_unet, full_unet):
+    """csrc/unet_exec.cpp replays UNet.forward's launch sequence: outputs must match the per-op path bit for bit,
+    in eval mode, with stochastic depth, with per-sample timesteps, and after in-place weight updates."""
+    for net, shape in ((tiny_unet, (3, 8, 32, 32)), (full_unet, (2, 8, 32, 32))):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda()
+        for t in (torch.full((shape[0],), 489), torch.tensor([0, 999, 40][: shape[0]])):
+            for training in (False, True):
+                net.train(training)
+                outs = []
+                for native in (True, False):
+                    net.native_forward = native
+                    random.seed(17)
+                    with torch.no_grad():
+                        outs.append(net(x, t.cuda()))
+                net.native_forward = True
+                assert torch.equal(outs[0], outs[1]), (shape, training)
+    blk = tiny_unet.encoder_stages[0].stage.blocks[0]
+    with torch.no_grad():
+        blk.conv.weight.mul_(1.5)                      # packed copy must be refreshed (version check)
+        tiny_unet.eval()
+        outs = []
+        for native in (True, False):
+            tiny_unet.native_forward = native
+            random.seed(3)
+            outs.append(tiny_unet(x[:, :, :, :] if x.shape[0] == 3 else torch.randn(3, 8, 32, 32, device="cuda"), torch.full((x.shape[0],), 7).cuda())
+                        if False else tiny_unet(torch.ones(2, 8, 32, 32, device="cuda"), torch.full((2,), 7).cuda()))
+        tiny_unet.native_forward = True
+        assert torch.equal(outs[0], outs[1])
+        blk.conv.weight.div_(1.5)
