@@ -74,6 +74,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if world > 1:                      # bring RCCL up outside the timed region even when --warmup 0
+        dist.all_reduce(torch.zeros(1, device=dev))
     net = UNet()
     net.load_state_dict(synth.fill_state_dict(net.state_dict()))
     dec = Decoder()
