@@ -106,6 +106,10 @@ typedef struct ldm_gemm_desc {
      * reads them with scalar loads and no device-side table has to exist. */
     const float *const *w_table;
     const float *const *bias_table;
+    /* optional DEVICE scratch: lets few-tile / long-K problems (M <= 128) split the reduction over the grid
+     * and sum fp32 partial tiles in a fixed order (deterministic); NULL = never split */
+    void        *workspace;
+    long long    workspace_bytes;
 } ldm_gemm_desc;
 
 int         ldm_version(void);

@@ -44,6 +44,7 @@ class GemmDesc(ctypes.Structure):
         ("groups", ctypes.c_int),
         ("a_gstride", ctypes.c_longlong), ("w_gstride", ctypes.c_longlong), ("o_gstride", ctypes.c_longlong),
         ("b_gstride", ctypes.c_longlong), ("w_table", c_fp), ("bias_table", c_fp),
+        ("workspace", c_fp), ("workspace_bytes", ctypes.c_longlong),
     ]
 
 

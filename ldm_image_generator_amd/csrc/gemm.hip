@@ -211,6 +211,120 @@ int g_variant = 1;      // 0: tile-per-block kernel, 1: persistent LDS-DMA strea
 
 int ldm_gemm_stream_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st);
 
+namespace {
+
+void launch_any(const GemmP &p, int groups, bool gate, int a_mode, hipStream_t st)
+{
+    if (g_variant == 1 && ldm_gemm_stream_dispatch(p, groups, gate, a_mode, st)) return;
+    if (gate)
+        dispatch<true, LDM_A_ROWS>(p, groups, st);
+    else if (a_mode == LDM_A_CONV3X3)
+        dispatch<false, LDM_A_CONV3X3>(p, groups, st);
+    else
+        dispatch<false, LDM_A_ROWS>(p, groups, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// split-K for problems with few output tiles and a long reduction (small batch: M <= 128 rows against the
+// deep stages' K = 512 ... 3072, the tiny-M Encodings GEMMs): one tile per CU would stream its whole K
+// range serially at the per-CU fetch rate; instead the reduction is cut into S grid groups that write
+// fp32 partial tiles into the caller's workspace, and a second kernel sums them in a FIXED order and
+// applies bias / gate / activation / addend.  Deterministic; S depends only on (N, K), never on M.
+// ---------------------------------------------------------------------------------------------------
+struct SplitEpiP {
+    const float *pa, *pb;            // partials [S][M][N] (pb: gate "b" half)
+    int S, M, N, seg_mode, nseg, seg_len, act;
+    float slope;
+    const float *bias[LDM_MAX_SEG], *bias2[LDM_MAX_SEG];
+    const float *addend;
+    long long ldadd, ldo;
+    float *out;
+};
+
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const SplitEpiP q)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n4n = q.N >> 2;
+    if (idx >= (long long)q.M * n4n) return;
+    const int m = (int)(idx / n4n), n = (int)(idx - (long long)m * n4n) * 4;
+    const long long plane = (long long)q.M * q.N;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < q.S; ++s) {
+        const f32x4 v = *(const f32x4 *)(q.pa + s * plane + (long long)m * q.N + n);
+        a += v;
+        if (q.pb) b += *(const f32x4 *)(q.pb + s * plane + (long long)m * q.N + n);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int col = n + e;
+        float b1 = 0.f, b2 = 0.f;
+        if (q.seg_mode == LDM_SEG_K) {
+            for (int sg = 0; sg < q.nseg; ++sg)
+                if (q.bias[sg]) b1 += q.bias[sg][col];
+            // same association as the fused epilogue: ((b0 + b1) + b2) + b3
+        } else {
+            const int sg = col / q.seg_len, loc = col - sg * q.seg_len;
+            if (q.bias[sg]) b1 = q.bias[sg][loc];
+            if (q.pb && q.bias2[sg]) b2 = q.bias2[sg][loc];
+        }
+        float v = a[e] + b1;
+        if (q.pb)
+            v = v * fmaxf(b[e] + b2, 0.f);
+        else if (q.act == LDM_ACT_RELU)
+            v = fmaxf(v, 0.f);
+        else if (q.act == LDM_ACT_LRELU)
+            v = v > 0.f ? v : v * q.slope;
+        if (q.addend) v += q.addend[(long long)m * q.ldadd + col];
+        o[e] = v;
+    }
+    float *dst = q.out + (long long)m * q.ldo + n;
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+}
+
+bool splitk_launch(const ldm_gemm_desc &d, const GemmP &p, bool gate, hipStream_t st)
+{
+    if (d.o_mode != LDM_O_ROWS || d.a_mode != LDM_A_ROWS || d.w_table || (d.groups > 1) || d.M > 128) return false;
+    if (d.lda != d.K) return false;                                   // A columns must be the K axis, densely
+    const int nk = d.K >> 5, ntn = d.N / 64;
+    if (ntn < 1 || ntn > 96 || nk < 8) return false;
+    const int nseg_k = (p.seg_mode == LDM_SEG_K) ? p.nseg : 1;
+    const int steps_per_seg = nk / nseg_k;
+    int s2 = 1;                                                       // splits inside one K-segment: power of two
+    while (ntn * nseg_k * s2 * 2 <= 512 && steps_per_seg % (s2 * 2) == 0 && steps_per_seg / (s2 * 2) >= 2) s2 *= 2;
+    const int S = nseg_k * s2;
+    if (S < 2 || S > LDM_MAX_TABLE) return false;
+    const size_t plane = (size_t)d.M * d.N * sizeof(float);
+    if (plane * S * (gate ? 2 : 1) > (size_t)d.workspace_bytes) return false;
+    const int ks = (d.K / nseg_k) / s2;
+
+    auto partial = [&](const float *const *wsrc, float *dst) {
+        GemmP q = p;
+        q.K = ks; q.act = LDM_ACT_NONE; q.addend = nullptr; q.out = dst; q.ldo = d.N; q.o_mode = LDM_O_ROWS;
+        q.a_gstride = ks; q.o_gstride = (long long)d.M * d.N; q.b_gstride = 0;
+        for (int i = 0; i < LDM_MAX_SEG; ++i) { q.bias[i] = q.bias2[i] = nullptr; q.w2[i] = nullptr; q.w[i] = i < p.nseg ? wsrc[i] : nullptr; }
+        if (p.seg_mode == LDM_SEG_K) {                                // one group per (segment, sub-range): per-group weight pointers
+            q.use_table = 1; q.nseg = 1; q.seg_mode = LDM_SEG_N; q.seg_len = d.N; q.w_gstride = 0;
+            for (int g = 0; g < S; ++g) { q.wtab[g] = wsrc[g / s2] + (long long)(g % s2) * ks; q.btab[g] = nullptr; }
+        } else {
+            q.w_gstride = ks;                                         // every N-segment's weights advance along K with the group
+        }
+        launch_any(q, S, false, LDM_A_ROWS, st);
+    };
+    float *pa = (float *)d.workspace, *pb = gate ? pa + (size_t)S * d.M * d.N : nullptr;
+    partial(p.w, pa);
+    if (gate) partial(p.w2, pb);
+    SplitEpiP e{};
+    e.pa = pa; e.pb = pb; e.S = S; e.M = d.M; e.N = d.N; e.seg_mode = p.seg_mode; e.nseg = p.nseg; e.seg_len = p.seg_len;
+    e.act = d.act; e.slope = d.slope; e.addend = d.addend; e.ldadd = d.ldadd; e.ldo = d.ldo; e.out = d.out;
+    for (int i = 0; i < LDM_MAX_SEG; ++i) { e.bias[i] = p.bias[i]; e.bias2[i] = p.bias2[i]; }
+    const long long work = (long long)d.M * (d.N / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, e);
+    return true;
+}
+
+}  // namespace
+
 extern "C" int ldm_gemm_variant(int v)
 {
     const int old = g_variant;
@@ -324,15 +438,7 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
         }
     }
     if (gate && d->a_mode == LDM_A_CONV3X3) { ldm_set_error("ldm_gemm_f32: GATE with conv3x3 unsupported"); return LDM_EINVAL; }
-    if (g_variant == 1 && ldm_gemm_stream_dispatch(p, groups, gate, d->a_mode, st)) {
-        // launched on the stream kernel
-    } else if (gate) {
-        dispatch<true, LDM_A_ROWS>(p, groups, st);
-    } else if (d->a_mode == LDM_A_CONV3X3) {
-        dispatch<false, LDM_A_CONV3X3>(p, groups, st);
-    } else {
-        dispatch<false, LDM_A_ROWS>(p, groups, st);
-    }
+    if (!(d->workspace && splitk_launch(*d, p, gate, st))) launch_any(p, groups, gate, d->a_mode, st);
     if (rec) (void)hipEventRecord(rec->stop, st);
     LDM_CHECK_LAUNCH("ldm_gemm_f32");
     return LDM_OK;

@@ -46,7 +46,10 @@ struct Layout {
     float *codes[LDM_MAX_LEVELS], *ench[LDM_MAX_LEVELS], *film[LDM_MAX_LEVELS];
     float *act[LDM_MAX_LEVELS][3];
     float *xf, *hidden, *qkv, *ctx, *pooled;
+    float *scratch;             // split-K scratch for the small-M GEMMs (same size / rule as ops.py: 32 MiB, M <= 128, K >= 256)
 };
+
+constexpr size_t kScratchBytes = 32u << 20;
 
 bool carve(const ldm_unet_plan *pl, const Level *lv, Bump &b, Layout &L)
 {
@@ -69,6 +72,7 @@ bool carve(const ldm_unet_plan *pl, const Level *lv, Bump &b, Layout &L)
     L.qkv = b.take(m3c);
     L.ctx = b.take(mc);
     L.pooled = b.take(mpool ? mpool : 64);
+    L.scratch = b.take(kScratchBytes / sizeof(float));
     return b.ok;
 }
 
@@ -103,6 +107,15 @@ ldm_gemm_desc gemm_rows(const float *a, long long M, int N, int K, const float *
     return d;
 }
 
+// the small-M rule of ops.gemm: hand the GEMM a scratch so that it may split its reduction over the grid
+void allow_splitk(ldm_gemm_desc &d, const Layout &L)
+{
+    if (d.M <= 128 && d.K >= 256 && d.groups == 1) {
+        d.workspace = L.scratch;
+        d.workspace_bytes = (long long)kScratchBytes;
+    }
+}
+
 // one SwinBlock (unet.py:42-47) on channels-last rows; y may not alias x
 int run_block(const ldm_unet_plan *pl, const ldm_unet_block *bk, int decision, const float *film, const int *slot, const float *x,
               float *y, const Level &lv, int B, const Layout &L, void *st)
@@ -119,10 +132,12 @@ int run_block(const ldm_unet_plan *pl, const ldm_unet_block *bk, int decision, c
     }
     if (bk->attention) {
         ldm_gemm_desc q = gemm_rows(L.xf, M, 3 * C, C, bk->in_w, bk->in_b, L.qkv);
+        allow_splitk(q, L);
         RUN(ldm_gemm_f32(&q, st));
         RUN(ldm_window_attention_f32(L.qkv, bk->in_b, L.xf, L.ctx, B, lv.H, lv.W, C, pl->window, bk->shift, st));
         ldm_gemm_desc o = gemm_rows(L.ctx, M, C, C, bk->out_w, bk->out_b, y);
         o.addend = y; o.ldadd = C;
+        allow_splitk(o, L);
         RUN(ldm_gemm_f32(&o, st));
     }
     const int e1 = decision >> 2, e2 = decision & 3;
@@ -134,11 +149,13 @@ int run_block(const ldm_unet_plan *pl, const ldm_unet_block *bk, int decision, c
             g.w[s] = bk->a_w[sel[s]]; g.bias[s] = bk->a_b[sel[s]];
             g.w2[s] = bk->b_w[sel[s]]; g.bias2[s] = bk->b_b[sel[s]];
         }
+        allow_splitk(g, L);
         RUN(ldm_gemm_f32(&g, st));
         ldm_gemm_desc c = gemm_rows(L.hidden, M, C, 3 * C, nullptr, nullptr, y);
         c.nseg = 3; c.seg_mode = LDM_SEG_K; c.seg_len = C; c.ldw = C;
         for (int s = 0; s < 3; ++s) { c.w[s] = bk->c_w[sel[s]]; c.bias[s] = bk->c_b[sel[s]]; }
         c.addend = y; c.ldadd = C;
+        allow_splitk(c, L);
         RUN(ldm_gemm_f32(&c, st));
     }
     return LDM_OK;
@@ -211,6 +228,7 @@ extern "C" int ldm_unet_forward_f32(const ldm_unet_plan *pl, const float *x, con
         if (i + 1 < n) {                                                    // unet.py:83, pool commuted in front of the 1x1 conv
             RUN(ldm_avgpool2_f32(L.act[i][cur[i]], L.pooled, B, lv[i].H, lv[i].W, lv[i].C, st));
             ldm_gemm_desc d = gemm_rows(L.pooled, lv[i + 1].M, lv[i + 1].C, lv[i].C, pl->down_w[i], pl->down_b[i], L.act[i + 1][0]);
+            allow_splitk(d, L);
             RUN(ldm_gemm_f32(&d, st));
             cur[i + 1] = 0;
         }

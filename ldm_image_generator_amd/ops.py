@@ -39,6 +39,18 @@ def _opt(t, name, dtype=torch.float32):
     return None if t is None else _dev(t, name, dtype)
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, nbytes=32 << 20):
+    """Per-(device, stream) split-K scratch for small-M GEMMs (ldm_gemm_desc.workspace)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None:
+        buf = _SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
 def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=None, biases2=None, ldw=None,
          seg_mode=SEG_N, act=ACT_NONE, slope=0.0, addend=None, ldadd=None, a_mode=A_ROWS, conv_hw=None, cin=0,
          o_mode=O_ROWS, out_hw=None, cout=0, groups=1, a_gstride=0, w_gstride=0, o_gstride=0, b_gstride=0,
@@ -83,6 +95,9 @@ def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=
     d.Cout = cout
     d.groups = groups
     d.a_gstride, d.w_gstride, d.o_gstride, d.b_gstride = a_gstride, w_gstride, o_gstride, b_gstride
+    if M <= 128 and K >= 256 and groups == 1:
+        ws = _scratch(a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     _lib.check(lib.ldm_gemm_f32(ctypes.byref(d), _stream()), "ldm_gemm_f32")
     return out
 

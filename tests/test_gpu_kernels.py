@@ -295,3 +295,36 @@ def test_gemm_schedules_bit_identical(gpu_device):
         assert torch.equal(outs[0], outs[1]), (M, N, K)
         ref = a.double() @ w.double().t() + b.double() + add.double()
         assert rel_l2(outs[1].double(), ref) < KTOL
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(16, 1024, 3072, "kseg"), (64, 512, 1536, "kseg"), (64, 1536, 512, "gate"), (16, 3072, 1024, "gate"),
+                                         (100, 256, 1024, "plain"), (128, 4096, 2048, "relu")])
+def test_gemm_split_k_small_m(ops, gpu_device, M, N, K, mode):
+    """Few tiles + long reduction: the split-K path (partials in the caller's scratch, fixed-order sum) against fp64."""
+    a = rnd(M, K)
+    add = rnd(M, N, seed=5)
+    if mode == "kseg":
+        c = K // 3
+        ws = [rnd(N, c, seed=10 + i, scale=K ** -0.5) for i in range(3)]
+        bs = [rnd(N, seed=20 + i) for i in range(3)]
+        out = add.cuda().clone()
+        ops.gemm(a.cuda(), M, N, K, [w.cuda() for w in ws], out, biases=[b.cuda() for b in bs], seg_mode=ops.SEG_K, addend=out)
+        ref = sum(a[:, i * c:(i + 1) * c].double() @ ws[i].double().t() + bs[i].double() for i in range(3)) + add.double()
+    elif mode == "gate":
+        f = N // 3
+        wa = [rnd(f, K, seed=10 + i, scale=K ** -0.5) for i in range(3)]
+        wb = [rnd(f, K, seed=20 + i, scale=K ** -0.5) for i in range(3)]
+        ba = [rnd(f, seed=30 + i) for i in range(3)]
+        bb = [rnd(f, seed=40 + i) for i in range(3)]
+        out = torch.empty(M, N, device=gpu_device)
+        dev = lambda ts: [t.cuda() for t in ts]
+        ops.gemm(a.cuda(), M, N, K, dev(wa), out, weights2=dev(wb), biases=dev(ba), biases2=dev(bb), act=ops.ACT_GATE)
+        ad = a.double()
+        ref = torch.cat([(ad @ wa[i].double().t() + ba[i].double()) * torch.relu(ad @ wb[i].double().t() + bb[i].double()) for i in range(3)], 1)
+    else:
+        w, b = rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)
+        out = torch.empty(M, N, device=gpu_device)
+        ops.gemm(a.cuda(), M, N, K, [w.cuda()], out, biases=[b.cuda()], addend=add.cuda(), act=ops.ACT_RELU if mode == "relu" else ops.ACT_NONE)
+        ref = a.double() @ w.double().t() + b.double()
+        ref = (torch.relu(ref) if mode == "relu" else ref) + add.double()
+    assert rel_l2(out.cpu(), ref) < KTOL

@@ -140,7 +140,8 @@ def test_ddim_sample_full_size_50_steps(full_unet):
 
 
 def test_batched_sampling_equals_per_sample(tiny_unet):
-    """Samples never interact: a batch equals its slices run alone."""
+    """Samples never interact: a batch equals its slices run alone.  Bitwise as long as both runs take the
+    same GEMM path; small batches may cross the split-K threshold (M <= 128 rows), which only re-associates the fp32 sums."""
     from ldm_image_generator_amd.ddpm import DDPM
     d = DDPM(model=tiny_unet)
     tiny_unet.eval()
@@ -148,7 +149,7 @@ def test_batched_sampling_equals_per_sample(tiny_unet):
     full = d.sample((4, 8, 32, 32), seed=1, num_steps=4, x_init=xT, progress=False).cpu()
     for lo in (0, 2):
         part = d.sample((2, 8, 32, 32), seed=1, num_steps=4, x_init=xT[lo:lo + 2], progress=False).cpu()
-        assert torch.equal(part, full[lo:lo + 2])
+        assert rel_l2(part, full[lo:lo + 2]) < 2e-6
 
 
 def test_decoder_tiny_and_resblock(gpu_device):
