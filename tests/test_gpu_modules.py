@@ -222,6 +222,28 @@ def test_unet_non_square_and_batch_one(gpu_device):
         assert rel_l2(y, ref) < 2e-5, (b, h, w)
 
 
+def test_cfg2_pixel_space_geometry_full_width(gpu_device):
+    """BASELINE cfg 2: default-width UNet(input_channels=3) on 64x64 pixels (R = 64/32/16/8: window padding 64->66 with
+    121 windows at stage 0, 8->12 at the deepest level; no VAE) -- forward and a 3-step DDIM loop vs the oracle run live."""
+    from ldm_image_generator_amd import synth
+    from ldm_image_generator_amd.ddpm import DDPM
+    from ldm_image_generator_amd.unet import UNet
+    net = formula(UNet(input_channels=3)).eval()
+    sd = synth.fill_state_dict(net.state_dict())
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(64))
+    t = torch.tensor([999, 311])
+    with torch.no_grad():
+        random.seed(4)
+        y = net(x.cuda(), t.cuda()).cpu()
+        random.seed(4)
+        ref = O.unet_forward(sd, x, t, training=False)
+    assert rel_l2(y, ref) < 2e-5
+    d = DDPM(model=net)
+    x0 = d.sample((2, 3, 64, 64), seed=0, num_steps=3, x_init=x, progress=False).cpu()
+    ref0 = O.ddim_sample(sd, (2, 3, 64, 64), seed=0, num_steps=3, training=False, x_init=x, prefix="")
+    assert rel_l2(x0, ref0) < 1e-4 and max_rel(x0, ref0) < 1e-3
+
+
 def test_sample_schedule_list_eta_and_errors(tiny_unet):
     """ddpm.py:68-71 (explicit schedule list, unknown schedule -> TypeError) and eta > 0 (sigma * e term) with injected noise."""
     from ldm_image_generator_amd import synth

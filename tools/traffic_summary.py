@@ -10,14 +10,19 @@ import json
 import sys
 
 
+def short_name(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[name.find("gemm"):].split("(")[0] if "gemm" in name else name.split("(")[0].split("<")[0][-48:]
+
+
 def per_kernel(pattern, counter):
-    f = glob.glob(pattern)[0]
+    f = glob.glob(pattern, recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = name[name.find("gemm"):].split("(")[0] if "gemm" in name else name.split("(")[0][-40:]
+        key = short_name(name)
         a = agg[key]
         a[0] += 1
         a[1] += float(r["Counter_Value"]) * 1024.0
@@ -27,8 +32,8 @@ def per_kernel(pattern, counter):
 
 if __name__ == "__main__":
     fetch_dir, write_dir, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    F = per_kernel(fetch_dir + "/*/*counter_collection.csv", "FETCH_SIZE")
-    W = per_kernel(write_dir + "/*/*counter_collection.csv", "WRITE_SIZE")
+    F = per_kernel(fetch_dir + "/**/*counter_collection*.csv", "FETCH_SIZE")
+    W = per_kernel(write_dir + "/**/*counter_collection*.csv", "WRITE_SIZE")
     rows, tot = [], [0, 0.0, 0.0]
     for k in sorted(F, key=lambda k: -F[k][2]):
         n, fb, ns = F[k]
