@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
                     help="eval: all 36 blocks run (headline, FLOPs deterministic); train: the reference's stochastic depth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-leg", action="store_true",
+                    help="skip the secondary measurement under GEMM schedule 2 (bf16x3 split consumer)")
     args = ap.parse_args()
 
     from ldm_image_generator_amd import dist as ldist
@@ -99,22 +101,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_pass(i)
-    fence()
-    ops.prof_enable(rank == 0)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_pass(100 + i)
-    fence()
-    dt = time.perf_counter() - t0
-    launches, gemm_ms, gemm_flops = ops.prof_read() if rank == 0 else (0, 0.0, 0.0)
-    ops.prof_enable(False)
-    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
+    def measure(warmup, steps):
+        """W untimed passes, then exactly K timed passes bracketed by barrier + synchronize; max over ranks."""
+        out = None
+        for i in range(warmup):
+            one_pass(i)
+        fence()
+        ops.prof_enable(rank == 0)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = one_pass(100 + i)
+        fence()
+        dt = time.perf_counter() - t0
+        prof = ops.prof_read() if rank == 0 else (0, 0.0, 0.0)
+        ops.prof_enable(False)
+        t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), prof, out
+
+    dt, (launches, gemm_ms, gemm_flops), out = measure(args.warmup, args.steps)
     finite = bool(torch.isfinite(out).all().item())
+
+    # secondary leg, never the headline: the same passes under GEMM schedule 2 (fp32 operands cut exactly into three
+    # bf16 pieces, six bf16 MFMAs per product, fp32 accumulate -- DESIGN.md 3.1), with its deviation from the
+    # exact-fp32 images of the same seed
+    split = None
+    if not args.no_split_leg:
+        keep = out[: min(16, out.shape[0])].clone()
+        del out
+        old = ops.gemm_variant(2)
+        dt2, (l2, ms2, fl2), out2 = measure(1, args.steps)
+        ops.gemm_variant(old)
+        d = (out2[: keep.shape[0]].double() - keep.double())
+        split = {"value": gb * args.steps / dt2, "unit": "images/s", "ms_per_step": dt2 / args.steps * 1e3,
+                 "gemm_tflops_fp32_equivalent": fl2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else None,
+                 "rel_l2_vs_exact_images": float(d.norm() / keep.double().norm()),
+                 "note": "GEMM schedule 2: v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits of the fp32 operands, "
+                         "fp32 accumulate; opt-in, not the headline"}
+        del out2
 
     if rank == 0:
         images = gb * args.steps
@@ -143,6 +168,8 @@ def main():
             line["roofline"]["traffic"] = tj["gemm_hbm_bytes_per_launch"]
             line["roofline"]["traffic_unit"] = "bytes per GEMM launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.md)"
             line["roofline"]["algorithmic_bytes_per_launch"] = None
+        if split is not None:
+            line["split_schedule"] = split
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64))
         print(json.dumps(line), flush=True)

@@ -117,8 +117,11 @@ const char *ldm_last_error(void);
 int         ldm_device_ok(void);          /* 1 if device 0 is gfx950 */
 
 int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
-/* schedule used by ldm_gemm_f32: 0 = one tile per workgroup, 1 = persistent LDS-DMA stream (default).
- * Both give bit-identical results; returns the previous setting (any other v only queries). */
+/* schedule used by ldm_gemm_f32: 0 = one tile per workgroup, 1 = persistent LDS-DMA stream (default); both use
+ * v_mfma_f32_32x32x2_f32 and give bit-identical results.  2 = the stream schedule with the "split" consumer:
+ * each fp32 operand value is cut exactly into three bf16 pieces in registers and a product is six
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-level error, not bit-identical to 0/1; shapes it does
+ * not cover run as 1).  Opt-in, process-wide; returns the previous setting (any other v only queries). */
 int ldm_gemm_variant(int v);
 
 /* hot-kernel timing for bench.py: when enabled every ldm_gemm_f32 launch is

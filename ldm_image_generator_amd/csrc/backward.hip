@@ -533,10 +533,11 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
     }
     __syncthreads();
     // ---- phase 2 (lane = key j): dk_j = sum_i dS[i][j] qs_i ; dv_j = sum_i P[i][j] dO_i ----------------
-    if (active && lane < L) {
-        f32x4 dk[8], dv[8];
+    f32x4 dk[8], dv[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) dk[c] = dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 8; ++c) dk[c] = dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool padded = active && lane < L && !ok;
+    if (active && lane < L) {
         for (int i = 0; i < L; ++i) {
             const float ds = dSs[i * (LMAX + 1) + lane], pp = Ps[i * (LMAX + 1) + lane];
 #pragma unroll
@@ -556,15 +557,28 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
                 *(f32x4 *)(o + C + 4 * c) = dk[c];
                 *(f32x4 *)(o + 2 * C + 4 * c) = dv[c];
             }
-        } else {                                  // zero-padded token: k, v are the in-proj bias
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(p.dbias_pad + C + head * 32 + 4 * c + e, dk[c][e]);
-                    atomicAdd(p.dbias_pad + 2 * C + head * 32 + 4 * c + e, dv[c][e]);
-                }
         }
+    }
+    // zero-padded tokens: k, v are the in-proj bias, so their dk / dv belong to its gradient.  Sum them over the wave's
+    // padded tokens through region A (free now) so that each wave issues 64 atomics, not 64 per padded token.
+    const bool any_pad = __any(padded) != 0;      // wave-uniform
+    __syncthreads();                              // every lane of the block is past its reads of region A
+    if (any_pad) {
+        if (active && lane < L) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 z{0.f, 0.f, 0.f, 0.f};
+                *(f32x4 *)(Qs + lane * RS + 4 * c) = padded ? dk[c] : z;
+                *(f32x4 *)(dOs + lane * RS + 4 * c) = padded ? dv[c] : z;
+            }
+        }
+    }
+    __syncthreads();
+    if (any_pad) {
+        const float *src = (lane < 32 ? Qs : dOs) + (lane & 31);
+        float acc = 0.f;
+        for (int r = 0; r < L; ++r) acc += src[r * RS];
+        atomicAdd(p.dbias_pad + (lane < 32 ? C : 2 * C) + head * 32 + (lane & 31), acc);
     }
 }
 

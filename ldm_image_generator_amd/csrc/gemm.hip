@@ -205,17 +205,17 @@ int dispatch(const GemmP &p, int groups, hipStream_t st)
     return launch<4, 1, 1, 1, GATE, AMODE>(p, groups, st);
 }
 
-int g_variant = 1;      // 0: tile-per-block kernel, 1: persistent LDS-DMA stream kernel
+int g_variant = 1;      // 0: tile-per-block kernel, 1: persistent LDS-DMA stream kernel, 2: stream kernel, bf16x3 split consumer
 
 }  // namespace
 
-int ldm_gemm_stream_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st);
+int ldm_gemm_stream_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st, bool split);
 
 namespace {
 
 void launch_any(const GemmP &p, int groups, bool gate, int a_mode, hipStream_t st)
 {
-    if (g_variant == 1 && ldm_gemm_stream_dispatch(p, groups, gate, a_mode, st)) return;
+    if (g_variant >= 1 && ldm_gemm_stream_dispatch(p, groups, gate, a_mode, st, g_variant == 2)) return;
     if (gate)
         dispatch<true, LDM_A_ROWS>(p, groups, st);
     else if (a_mode == LDM_A_CONV3X3)
@@ -328,7 +328,7 @@ bool splitk_launch(const ldm_gemm_desc &d, const GemmP &p, bool gate, hipStream_
 extern "C" int ldm_gemm_variant(int v)
 {
     const int old = g_variant;
-    if (v == 0 || v == 1) g_variant = v;
+    if (v >= 0 && v <= 2) g_variant = v;
     return old;
 }
 

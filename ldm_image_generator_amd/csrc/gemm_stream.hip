@@ -32,7 +32,56 @@ __device__ __forceinline__ void glds16(const float *src, float *lds_dst)
 }
 
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
+// ---- "split" consumer (SPLIT = true) -------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores: every fp32 operand value is cut, exactly, into three bf16 pieces
+// x = hi + mid + lo (8 + 8 + 8 mantissa bits, truncating), and a product tile is six
+// v_mfma_f32_32x32x16_bf16 (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; small terms first; fp32
+// accumulate).  Only mid*lo, lo*mid, lo*lo are dropped (<= 2^-24 relative each), so results carry
+// fp32-level error but are NOT bit-identical to the v_mfma_f32_32x32x2_f32 schedule.  Operands still arrive
+// as fp32 (same LDS ring, same swizzle, weights in place): the split happens in registers per fragment.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Split3 {
+    bf16x8 hi, mid, lo;
+};
+
+__device__ __forceinline__ void split3(const f32x4 &c0, const f32x4 &c1, Split3 &o)
+{
+    u32x4 H, M, L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hh[2], mm[2], ll[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = 2 * i + j;
+            const float v = e < 4 ? c0[e & 3] : c1[e & 3];
+            hh[j] = __float_as_uint(v) & 0xFFFF0000u;
+            const float r1 = v - __uint_as_float(hh[j]);          // exact
+            mm[j] = __float_as_uint(r1) & 0xFFFF0000u;
+            const float r2 = r1 - __uint_as_float(mm[j]);         // exact, <= 8 significant bits: a bf16
+            ll[j] = __float_as_uint(r2);
+        }
+        H[i] = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u);   // two high halves -> one dword
+        M[i] = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u);
+        L[i] = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u);
+    }
+    o.hi = __builtin_bit_cast(bf16x8, H);
+    o.mid = __builtin_bit_cast(bf16x8, M);
+    o.lo = __builtin_bit_cast(bf16x8, L);
+}
+
+__device__ __forceinline__ void mfma6(const Split3 &a, const Split3 &b, f32x16 &c)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -151,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     // ---- consumer ------------------------------------------------------------
     f32x16 acc[NACC][TM][TN];
     float pre[TM][TN][16];
-    f32x4 fa0[TM], fb0[NACC][TN], fa1[TM], fb1[NACC][TN];        // two fragment sets (ping-pong over j)
+    f32x4 fa0[TM], fb0[NACC][TN], fa1[TM], fb1[NACC][TN];        // two fragment sets (ping-pong over j); SPLIT: the two chunks of a half
+    Split3 sa[SPLIT ? TM : 1], sb[SPLIT ? NACC : 1][SPLIT ? TN : 1];
     if (my_tiles == 0) return;
     // accumulators are cleared here and again right after each tile's epilogue -- NOT by a per-step
     // "c_kt == 0 ? 0 : acc" select, which would put 16 VALU selects per accumulator tile (each waiting
@@ -206,11 +256,64 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         asm volatile("" ::: "memory");
     };
 
+    // SPLIT: a K-step is two halves of 16 k each; lane group h owns chunks {4*hf + h, 4*hf + 2 + h} of a row
+    // (any assignment works as long as A and W use the same one)
+    auto read_half = [&](int step, int hf) {
+        const float *As = lds + (step & 1) * STAGE, *Bs = As + BM * 32;
+        const int c0 = 4 * hf + h, c1 = c0 + 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            fa0[i] = *(const f32x4 *)(As + swz((wm * TM + i) * 32 + r, c0));
+            fa1[i] = *(const f32x4 *)(As + swz((wm * TM + i) * 32 + r, c1));
+        }
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                fb0[q][i] = *(const f32x4 *)(Bs + swz(q * BN + (wn * TN + i) * 32 + r, c0));
+                fb1[q][i] = *(const f32x4 *)(Bs + swz(q * BN + (wn * TN + i) * 32 + r, c1));
+            }
+    };
+    auto split_all = [&]() {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) split3(fa0[i], fa1[i], sa[i]);
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) split3(fb0[q][i], fb1[q][i], sb[q][i]);
+        }
+    };
+    // part 0 / 1: first / second half of the wave's accumulator tiles (part < 0: all of them)
+    auto mma_split = [&](int part) {
+        if constexpr (SPLIT) {
+            constexpr int NT = NACC * TM * TN;
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        const int idx = (q * TM + i) * TN + jj;
+                        const bool first = idx < (NT + 1) / 2;
+                        if (part < 0 || (part == 0) == first) mfma6(sa[i], sb[q][jj], acc[q][i][jj]);
+                    }
+        }
+    };
+    // one K-step of the split consumer up to (not including) the next stage's first fragment read
+    auto split_step_head = [&](int s_) {
+        split_all();                                      // half 0 (read during the previous step)
+        read_half(s_, 1);                                 // in flight under the MFMAs below
+        mma_split(-1);
+        split_all();                                      // half 1
+        mma_split(0);
+    };
+
     // ---- prologue: stage 0 <- step 0 -------------------------------------------
     loader_setup();
     loader_issue();
     sync_point();
-    read_frags(0, 0, fa0, fb0);
+    if constexpr (SPLIT) read_half(0, 0); else read_frags(0, 0, fa0, fb0);
 
     // Tile loop outside, K-steps inside: the accumulators are loop-carried in FIXED registers through a
     // single-path inner loop (one merged loop with a "last step?" branch made hipcc shuttle all accumulator
@@ -224,10 +327,17 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
 #pragma unroll 1
         for (int kt = 0; kt < nk - 1; ++kt, ++s) {
             loader_issue();                               // step s+1 (exists: this is not the tile's last step)
-            quarters_0_to_2(s);
-            sync_point();
-            read_frags(s + 1, 0, fa0, fb0);
-            mma(fa1, fb1);
+            if constexpr (SPLIT) {
+                split_step_head(s);
+                sync_point();
+                read_half(s + 1, 0);
+                mma_split(1);
+            } else {
+                quarters_0_to_2(s);
+                sync_point();
+                read_frags(s + 1, 0, fa0, fb0);
+                mma(fa1, fb1);
+            }
         }
         // last K-step of the tile: bias/addend prefetch, MFMAs and epilogue on ONE control path, so the
         // only wait for the prefetched registers sits in front of their first use
@@ -238,23 +348,30 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         EpiCols<TN> cols;
         gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
         if (use_pre) gemm_prefetch_addend<WM, WN, TM, TN>(p, pre, c_m0, c_n0, c_g, wm, wn, r, h);
-        quarters_0_to_2(s);
-        sync_point();
-        if (more) read_frags(s + 1, 0, fa0, fb0);
-        mma(fa1, fb1);
+        if constexpr (SPLIT) {
+            split_step_head(s);
+            sync_point();
+            if (more) read_half(s + 1, 0);
+            mma_split(1);
+        } else {
+            quarters_0_to_2(s);
+            sync_point();
+            if (more) read_frags(s + 1, 0, fa0, fb0);
+            mma(fa1, fb1);
+        }
         gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
         ++s;
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false>
 int launch_stream(const GemmP &p, int groups, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
     static int slots = 0;
-    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE>;
+    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT>;
     if (slots == 0) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int dev = 0, cus = 256;
@@ -277,9 +394,16 @@ int launch_stream(const GemmP &p, int groups, hipStream_t st)
 
 // Chooses a stream-kernel instance for the problem; returns 1 if it launched, 0 if the caller should
 // fall back to the tile-per-block kernel.
-int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, hipStream_t st)
+int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, hipStream_t st, bool split)
 {
     const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
+    if (split && p.M > 128) {
+        // split schedule: wave tiles of 64x64 (or 64x32 x two gate matrices) so that each split fragment feeds two
+        // tiles; shapes it does not cover (grouped conv N = 32, tiny M) fall through to the exact-fp32 instances
+        if (gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS, true>(p, groups, st);
+        if (!gate && amode == LDM_A_CONV3X3 && unit % 128 == 0) return launch_stream<2, 2, 2, 2, false, LDM_A_CONV3X3, true>(p, groups, st);
+        if (!gate && amode == LDM_A_ROWS && unit % 128 == 0) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, true>(p, groups, st);
+    }
     if (gate) {
         if (amode != LDM_A_ROWS) return 0;
         if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS>(p, groups, st);

@@ -297,6 +297,76 @@ def test_gemm_schedules_bit_identical(gpu_device):
         assert rel_l2(outs[1].double(), ref) < KTOL
 
 
+def test_gemm_split_schedule_fp32_level_error(gpu_device):
+    """Schedule 2 (fp32 operands cut exactly into three bf16 pieces, six bf16 MFMAs per product, fp32 accumulate):
+    same stated kernel tolerance as the exact-fp32 schedules, and its error against fp64 stays within a small
+    multiple of theirs.  Covers plain / K-segment / gated / 3x3-conv instances, ragged M, many tiles per workgroup."""
+    from ldm_image_generator_amd import ops as o
+
+    def both(fn):
+        outs = []
+        for v in (1, 2):
+            old = o.gemm_variant(v)
+            outs.append(fn())
+            o.gemm_variant(old)
+        return outs
+
+    def check(outs, ref, what):
+        e1, e2 = rel_l2(outs[0].double().cpu(), ref), rel_l2(outs[1].double().cpu(), ref)
+        assert e2 < KTOL and e2 < 4 * e1 + 1e-7, (what, e1, e2)
+        assert not torch.equal(outs[0], outs[1]), what + ": schedule 2 did not run"
+
+    for (M, N, K) in [(70000, 128, 128), (4100, 1024, 64), (257, 256, 96), (33000, 384, 32)]:
+        a, w, b = rnd(M, K).cuda(), rnd(N, K, seed=1, scale=K ** -0.5).cuda(), rnd(N, seed=2).cuda()
+        add = rnd(M, N, seed=3).cuda()
+
+        def plain():
+            out = torch.empty(M, N, device=gpu_device)
+            o.gemm(a, M, N, K, [w], out, biases=[b], addend=add)
+            return out
+        check(both(plain), (a.double() @ w.double().t() + b.double() + add.double()).cpu(), ("plain", M, N, K))
+    # gated, N-segments by pointer + K-segment second GEMM (the RandomMoE pair)
+    M, C = 5000, 128
+    x = rnd(M, C).cuda()
+    wa = [rnd(C, C, seed=10 + i, scale=C ** -0.5).cuda() for i in range(3)]
+    wb = [rnd(C, C, seed=20 + i, scale=C ** -0.5).cuda() for i in range(3)]
+    wc = [rnd(C, C, seed=30 + i, scale=C ** -0.5).cuda() for i in range(3)]
+    ba = [rnd(C, seed=40 + i).cuda() for i in range(3)]
+
+    def gate():
+        hid = torch.empty(M, 3 * C, device=gpu_device)
+        o.gemm(x, M, 3 * C, C, wa, hid, weights2=wb, biases=ba, biases2=ba, act=o.ACT_GATE)
+        return hid
+    hs = both(gate)
+    xd = x.double()
+    href = torch.cat([(xd @ wa[i].double().t() + ba[i].double()) * torch.relu(xd @ wb[i].double().t() + ba[i].double()) for i in range(3)], 1)
+    check(hs, href.cpu(), "gate")
+
+    def kseg():
+        y = torch.empty(M, C, device=gpu_device)
+        o.gemm(hs[0], M, C, 3 * C, wc, y, biases=ba, seg_mode=o.SEG_K, addend=x)
+        return y
+    yref = sum(hs[0][:, i * C:(i + 1) * C].double() @ wc[i].double().t() + ba[i].double() for i in range(3)) + xd
+    check(both(kseg), yref.cpu(), "kseg")
+    # dense 3x3 conv (VAE ResBlock shape class), implicit im2col
+    B, R, C = 3, 20, 128
+    M = B * R * R
+    xc = rnd(M, C).cuda()
+    w4 = rnd(C, C, 3, 3, seed=5, scale=(9 * C) ** -0.5)
+    wk = w4.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().cuda()
+    bc = rnd(C, seed=6).cuda()
+
+    def conv():
+        y = torch.empty(M, C, device=gpu_device)
+        o.gemm(xc, M, C, 9 * C, [wk], y, lda=C, ldw=9 * C, biases=[bc], act=o.ACT_LRELU, slope=0.01, addend=xc,
+               a_mode=o.A_CONV3X3, conv_hw=(R, R), cin=C)
+        return y
+    xn = xc.cpu().double().reshape(B, R, R, C).permute(0, 3, 1, 2)
+    cref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xn, w4.double(), bc.cpu().double(), padding=1), 0.01)
+    cref = cref.permute(0, 2, 3, 1).reshape(M, C) + xc.cpu().double()
+    check(both(conv), cref, "conv3x3")
+
+
 @pytest.mark.parametrize("M,N,K,mode", [(16, 1024, 3072, "kseg"), (64, 512, 1536, "kseg"), (64, 1536, 512, "gate"), (16, 3072, 1024, "gate"),
                                          (100, 256, 1024, "plain"), (128, 4096, 2048, "relu")])
 def test_gemm_split_k_small_m(ops, gpu_device, M, N, K, mode):

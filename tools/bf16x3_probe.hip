@@ -48,20 +48,24 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &
     }
 }
 
-template <int TM, int SPLIT_A>
+template <int TM, int SPLIT_A, int TN>
 __global__ __launch_bounds__(256) void probe(float *out, int iters)
 {
     __shared__ __attribute__((aligned(16))) float lds[8192];
     for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = 1e-3f * (i % 977) - 0.4f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    f32x16 acc[TM];
-    for (int i = 0; i < TM; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f32x16 acc[TM * TN];
+    for (int i = 0; i < TM * TN; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     for (int it = 0; it < iters; ++it) {
-        // B: three pre-split planes (bf16x8 each) -> 3 x ds_read_b128
-        const bf16x8 bh = *(const bf16x8 *)(lds + ((lane * 4 + it * 64) & 8188));
-        const bf16x8 bm = *(const bf16x8 *)(lds + ((lane * 4 + it * 64 + 2048) & 8188));
-        const bf16x8 bl = *(const bf16x8 *)(lds + ((lane * 4 + it * 64 + 4096) & 8188));
+        // B: three pre-split planes (bf16x8 each) -> 3 x ds_read_b128 per fragment
+        bf16x8 bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *(const bf16x8 *)(lds + ((lane * 4 + it * 64 + j * 256) & 8188));
+            bm[j] = *(const bf16x8 *)(lds + ((lane * 4 + it * 64 + 2048 + j * 256) & 8188));
+            bl[j] = *(const bf16x8 *)(lds + ((lane * 4 + it * 64 + 4096 + j * 256) & 8188));
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             bf16x8 ah, am, al;
@@ -76,33 +80,37 @@ __global__ __launch_bounds__(256) void probe(float *out, int iters)
                 am = *(const bf16x8 *)(lds + ((lane * 4 + it * 96 + i * 512 + 1024) & 8188));
                 al = *(const bf16x8 *)(lds + ((lane * 4 + it * 96 + i * 512 + 3072) & 8188));
             }
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 &c = acc[i * TN + j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], c, 0, 0, 0);
+            }
         }
     }
     float s = 0.f;
-    for (int i = 0; i < TM; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    for (int i = 0; i < TM * TN; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int TM, int SPLIT_A>
+template <int TM, int SPLIT_A, int TN>
 void run(float *out, int bpc)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int blocks = 256 * bpc, iters = 40000 / TM;
-    hipLaunchKernelGGL((probe<TM, SPLIT_A>), dim3(blocks), dim3(256), 0, 0, out, 100);
+    const int blocks = 256 * bpc, iters = 40000 / (TM * TN);
+    hipLaunchKernelGGL((probe<TM, SPLIT_A, TN>), dim3(blocks), dim3(256), 0, 0, out, 100);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((probe<TM, SPLIT_A>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL((probe<TM, SPLIT_A, TN>), dim3(blocks), dim3(256), 0, 0, out, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)blocks * 4 * iters * TM * 2.0 * 32 * 32 * 16;      // fp32-equivalent
-    printf("TM %d  split-A-on-the-fly %d  blocks/CU %d: %.2f ms, %.1f fp32-equivalent TFLOP/s\n", TM, SPLIT_A, bpc, ms, flops / ms / 1e9);
+    const double flops = (double)blocks * 4 * iters * TM * TN * 2.0 * 32 * 32 * 16;      // fp32-equivalent
+    printf("TM %d TN %d  split-A-on-the-fly %d  blocks/CU %d: %.2f ms, %.1f fp32-equivalent TFLOP/s\n", TM, TN, SPLIT_A, bpc, ms, flops / ms / 1e9);
 }
 
 int main()
@@ -110,10 +118,12 @@ int main()
     float *out;
     hipMalloc(&out, 4096 * 1024 * sizeof(float));
     for (int bpc = 1; bpc <= 3; ++bpc) {
-        run<2, 0>(out, bpc);
-        run<2, 1>(out, bpc);
-        run<2, 2>(out, bpc);
-        run<4, 2>(out, bpc);
+        run<2, 0, 1>(out, bpc);
+        run<2, 1, 1>(out, bpc);
+        run<2, 2, 1>(out, bpc);
+        run<2, 2, 2>(out, bpc);
+        run<1, 2, 2>(out, bpc);
+        run<2, 0, 2>(out, bpc);
     }
     return 0;
 }

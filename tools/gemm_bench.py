@@ -1,5 +1,5 @@
 """Micro-benchmark of the GEMM family on the UNet / VAE shapes of BASELINE cfg 3 (B=256).
-Usage: python tools/gemm_bench.py [variant ...]   (variants: 0 = tile, 1 = stream)"""
+Usage: python tools/gemm_bench.py [variant ...]   (variants: 0 = tile, 1 = stream, 2 = stream + bf16x3 split consumer)"""
 import sys
 import os
 import torch
