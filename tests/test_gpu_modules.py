@@ -177,6 +177,37 @@ def test_decoder_full_size_and_uint8(gpu_device):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-2
 
 
+def test_split_schedule_meets_the_same_tolerances(full_unet, tiny_unet):
+    """GEMM schedule 2 (exact 3-way bf16 split of the fp32 operands on the bf16 matrix cores, fp32 accumulate) against the
+    reference's goldens at the SAME stated tolerances as the exact-fp32 schedule: full-size UNet forward, 50-step
+    sampling, full-size Decoder."""
+    from ldm_image_generator_amd import ops
+    from ldm_image_generator_amd.ddpm import DDPM
+    from ldm_image_generator_amd.vae import Decoder
+    old = ops.gemm_variant(2)
+    try:
+        g = load_golden("unet_full")
+        with torch.no_grad():
+            full_unet.eval()
+            random.seed(0)
+            assert rel_l2(full_unet(T(g["x"]).cuda(), T(g["t"]).cuda()).cpu(), T(g["y_eval"])) < 2e-5
+        g = load_golden("sample_full")
+        full_unet.train()
+        x0 = DDPM(model=full_unet).sample((1, 8, 32, 32), seed=0, num_steps=50, x_init=T(g["xT"]), progress=False).cpu()
+        assert rel_l2(x0, T(g["x0_train_50"])) < 1e-4 and max_rel(x0, T(g["x0_train_50"])) < 1e-3
+        g = load_golden("sample_tiny")
+        tiny_unet.eval()
+        x0 = DDPM(model=tiny_unet).sample((2, 8, 32, 32), seed=0, num_steps=50, x_init=T(g["xT"]), progress=False).cpu()
+        assert rel_l2(x0, T(g["x0_eval_50"])) < 1e-4 and max_rel(x0, T(g["x0_eval_50"])) < 1e-3
+        g = load_golden("decoder_full")
+        with torch.no_grad():
+            yc = formula(Decoder())(T(g["z"]).cuda()).cpu()
+        assert rel_l2(yc[:, :, ::4, ::4], T(g["y_sub"])) < 1e-5
+        assert abs(float(yc.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
+    finally:
+        ops.gemm_variant(old)
+
+
 def test_unet_vs_oracle_fresh_inputs_per_sample_t(tiny_unet):
     """Per-sample timesteps (training-style), oracle evaluated live on the host."""
     from ldm_image_generator_amd import synth
