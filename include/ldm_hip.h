@@ -123,6 +123,9 @@ int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-level error, not bit-identical to 0/1; shapes it does
  * not cover run as 1).  Opt-in, process-wide; returns the previous setting (any other v only queries). */
 int ldm_gemm_variant(int v);
+/* epilogue of the stream schedule for plain-rows outputs: 1 (default) = through LDS, 16 bytes per lane per store;
+ * 0 = direct from the MFMA layout, 4 bytes per lane.  Bit-identical results; A/B knob.  Returns the previous setting. */
+int ldm_gemm_wide_epilogue(int v);
 
 /* hot-kernel timing for bench.py: when enabled every ldm_gemm_f32 launch is
  * bracketed by hipEvents on ITS stream; ldm_prof_read synchronises those events

@@ -82,6 +82,7 @@ SIGNATURES = {
     "ldm_device_ok": (_I, []),
     "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "ldm_gemm_variant": (_I, [_I]),
+    "ldm_gemm_wide_epilogue": (_I, [_I]),
     "ldm_unet_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(UNetPlanDesc), _I, _I, _I, _I]),
     "ldm_unet_forward_f32": (_I, [ctypes.POINTER(UNetPlanDesc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I, _P,
                                   ctypes.c_size_t, _P, _P]),

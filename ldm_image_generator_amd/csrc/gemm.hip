@@ -302,6 +302,7 @@ bool splitk_launch(const ldm_gemm_desc &d, const GemmP &p, bool gate, hipStream_
         GemmP q = p;
         q.K = ks; q.act = LDM_ACT_NONE; q.addend = nullptr; q.out = dst; q.ldo = d.N; q.o_mode = LDM_O_ROWS;
         q.a_gstride = ks; q.o_gstride = (long long)d.M * d.N; q.b_gstride = 0;
+        q.wide_ok = ldm_aligned16(dst) && q.o_gstride % 4 == 0;
         for (int i = 0; i < LDM_MAX_SEG; ++i) { q.bias[i] = q.bias2[i] = nullptr; q.w2[i] = nullptr; q.w[i] = i < p.nseg ? wsrc[i] : nullptr; }
         if (p.seg_mode == LDM_SEG_K) {                                // one group per (segment, sub-range): per-group weight pointers
             q.use_table = 1; q.nseg = 1; q.seg_mode = LDM_SEG_N; q.seg_len = d.N; q.w_gstride = 0;
@@ -324,6 +325,10 @@ bool splitk_launch(const ldm_gemm_desc &d, const GemmP &p, bool gate, hipStream_
 }
 
 }  // namespace
+
+int ldm_gemm_stream_wide(int v);
+
+extern "C" int ldm_gemm_wide_epilogue(int v) { return ldm_gemm_stream_wide(v); }
 
 extern "C" int ldm_gemm_variant(int v)
 {
@@ -410,6 +415,8 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
     }
     p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.o_gstride = d->o_gstride; p.b_gstride = d->b_gstride;
     p.use_table = d->w_table ? 1 : 0;
+    p.wide_ok = d->o_mode == LDM_O_ROWS && ldm_aligned16(d->out) && d->ldo % 4 == 0 && d->o_gstride % 4 == 0 &&
+                (!d->addend || (ldm_aligned16(d->addend) && d->ldadd % 4 == 0));
     if (d->w_table) {
         LDM_REQUIRE(groups <= LDM_MAX_TABLE, "ldm_gemm_f32: pointer-table mode supports at most %d groups", LDM_MAX_TABLE);
         for (int i = 0; i < groups; ++i) {

@@ -25,6 +25,7 @@ struct GemmP {
     int o_mode, OH, OW, Cout;
     long long a_gstride, w_gstride, o_gstride, b_gstride;
     int use_table;                              // pointer-table mode: per-group weights / biases below
+    int wide_ok;                                // rows output (and addend) 16-byte addressable: the stream kernel may use its wide epilogue
     const float *wtab[LDM_MAX_TABLE];
     const float *btab[LDM_MAX_TABLE];
 };
@@ -225,6 +226,116 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x16 (&acc)[GATE
                     }
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "Wide" epilogue of the stream kernel (o_mode == ROWS): the MFMA C/D map gives a lane ONE column and 16 rows, so a
+// direct epilogue is 16 global_store_dword (+ 16 global_load_dword for an addend) per 32x32 tile and wave -- 128-byte
+// row fragments, store-issue bound.  Here each wave passes its values through LDS (its own 1-KiB slices of the ring
+// stage the tile has just finished with: no other wave writes them before this wave's next DMA) and leaves as
+// 16-byte-per-lane rows: 4 global_store_dwordx4 (+ 4 global_load_dwordx4) per tile and wave.  Arithmetic and its
+// order are unchanged (bias, activation / gate, then addend): results stay bit-identical to the direct epilogue.
+//
+// Scratch layout per wave: local row rho (0..31) of the strip sits in "slot" = rho with bits 0 and 2 swapped (rows
+// rho and rho + 4 -- the two half-waves of one ds_write -- land in different bank halves); slots are rows of 32*TN
+// floats packed into the wave's 1-KiB slices (slice i of wave w starts at float (i * 4 + w) * 256).
+template <int TN>
+struct WideLane {
+    int cc, rsub;          // this lane's 16-byte chunk column inside the strip row, row inside an instruction's row group
+    int rd_off;            // float offset of its b128 reads inside the wave's scratch (without the per-k constant)
+    int wr_off;            // float offset of its b32 writes (without the per-(e, jn) constant)
+};
+
+template <int TN>
+__device__ __forceinline__ WideLane<TN> wide_lane(int lane)
+{
+    constexpr int CPR = 8 * TN;
+    WideLane<TN> w;
+    w.cc = lane % CPR;
+    w.rsub = lane / CPR;
+    const int r = lane & 31, h = lane >> 5;
+    if (TN == 1) {
+        const int sw = (w.rsub & 2) | ((w.rsub & 1) << 2) | ((w.rsub >> 2) & 1);
+        w.rd_off = sw * 32 + 4 * w.cc;
+        w.wr_off = h * 32 + r;
+    } else {
+        w.rd_off = (w.rsub & 1) * 1024 + (w.rsub & 2) * 64 + 4 * w.cc;
+        w.wr_off = h * 64 + r;
+    }
+    return w;
+}
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_prefetch_addend_wide(const GemmP &p, float (&pre)[TM][TN][16], int m0, int n0, int g, int wm, int wn,
+                                                          const WideLane<TN> &wl)
+{
+    constexpr int RPI = 8 / TN;                 // rows per instruction
+    const int row0 = m0 + wm * TM * 32 + wl.rsub;
+    const int lda_ = (int)p.ldadd;
+    const bool full = m0 + WM * TM * 32 <= p.M;
+    const int rclamp = row0 < p.M ? row0 : p.M - 1;
+    const float *base = p.addend + (long long)rclamp * p.ldadd + g * p.o_gstride + n0 + wn * TN * 32 + 4 * wl.cc;
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int k = 0; k < 4 * TN; ++k) {
+            int roff = im * 32 + k * RPI;
+            if (!full) roff = row0 + roff < p.M ? roff : (p.M - 1 - rclamp);
+            const f32x4 v = *(const f32x4 *)(base + roff * lda_);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pre[im][(4 * k + c) >> 4][(4 * k + c) & 15] = v[c];
+        }
+}
+
+template <int WM, int WN, int TM, int TN, bool GATE>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int n0, int g, int wm, int wn,
+                                                   const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre,
+                                                   const WideLane<TN> &wl, float *scratch /* stage base + wave * 256 */)
+{
+    constexpr int NACC = GATE ? 2 : 1;
+    constexpr int RPI = 8 / TN;
+    float b1[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) b1[jn] = ((c.braw[0][jn] + c.braw[1][jn]) + c.braw[2][jn]) + c.braw[3][jn];
+    const int row0 = m0 + wm * TM * 32 + wl.rsub;
+    const bool full = m0 + WM * TM * 32 <= p.M;
+    const int ldo_ = (int)p.ldo;
+    float *obase = p.out + (long long)row0 * p.ldo + g * p.o_gstride + n0 + wn * TN * 32 + 4 * wl.cc;
+    float *wr = scratch + wl.wr_off;
+    const float *rd = scratch + wl.rd_off;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                float v = acc[0][im][jn][e] + b1[jn];
+                if (GATE) {
+                    const float gt = acc[NACC - 1][im][jn][e] + c.b2[jn];
+                    v = v * fmaxf(gt, 0.f);
+                } else if (p.act == LDM_ACT_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (p.act == LDM_ACT_LRELU) {
+                    v = v > 0.f ? v : v * p.slope;
+                }
+                // local row (e & 3) + 8 (e >> 2) + 4 h  ->  slot (bits 0, 2 swapped) = h | (e & 2) | (e & 1) << 2 | 8 (e >> 2)
+                int off;
+                if (TN == 1) off = (e >> 2) * 1024 + ((e & 2) | ((e & 1) << 2)) * 32;
+                else off = (2 * (e >> 2) + (e & 1)) * 1024 + (e & 2) * 64 + jn * 32;
+                wr[off] = v;
+            }
+#pragma unroll
+        for (int k = 0; k < 4 * TN; ++k) {
+            const int off = (TN == 1) ? k * 1024 : (k >> 1) * 2048 + (k & 1) * 64;
+            f32x4 v = *(const f32x4 *)(rd + off);
+            if (use_pre) {
+#pragma unroll
+                for (int cix = 0; cix < 4; ++cix) v[cix] += pre[im][(4 * k + cix) >> 4][(4 * k + cix) & 15];
+            }
+            const int roff = im * 32 + k * RPI;
+            if (full || row0 + roff < p.M) *(f32x4 *)(obase + roff * ldo_) = v;
         }
     }
 }

@@ -22,6 +22,7 @@ using namespace ldmgemm;
 namespace {
 
 constexpr int NS = 2;      // LDS ring stages
+int g_wide = 1;            // wide (LDS-transposed, 16-byte-per-lane) epilogue for rows outputs; 0 keeps the direct one (A/B tests)
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void mfma6(const Split3 &a, const Split3 &b, f32x16 &
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     constexpr int A_F4 = BM / 32, B_F4 = NB / 32;
     constexpr int STAGE = (BM + NB) * 32;
     constexpr int NACC = GATE ? 2 : 1;
+    static_assert(!WIDE || A_F4 + B_F4 >= 4 * TN, "wide epilogue: not enough per-wave LDS slices in one ring stage");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     // ---- consumer ------------------------------------------------------------
     f32x16 acc[NACC][TM][TN];
     float pre[TM][TN][16];
+    const WideLane<TN> wl = wide_lane<TN>(lane);
     f32x4 fa0[TM], fb0[NACC][TN], fa1[TM], fb1[NACC][TN];        // two fragment sets (ping-pong over j); SPLIT: the two chunks of a half
     Split3 sa[SPLIT ? TM : 1], sb[SPLIT ? NACC : 1][SPLIT ? TN : 1];
     if (my_tiles == 0) return;
@@ -347,7 +350,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
         EpiCols<TN> cols;
         gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
-        if (use_pre) gemm_prefetch_addend<WM, WN, TM, TN>(p, pre, c_m0, c_n0, c_g, wm, wn, r, h);
+        if constexpr (WIDE) {
+            if (use_pre) gemm_prefetch_addend_wide<WM, WN, TM, TN>(p, pre, c_m0, c_n0, c_g, wm, wn, wl);
+        } else {
+            if (use_pre) gemm_prefetch_addend<WM, WN, TM, TN>(p, pre, c_m0, c_n0, c_g, wm, wn, r, h);
+        }
         if constexpr (SPLIT) {
             split_step_head(s);
             sync_point();
@@ -359,19 +366,22 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
             if (more) read_frags(s + 1, 0, fa0, fb0);
             mma(fa1, fb1);
         }
-        gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
+        if constexpr (WIDE)      // scratch: this wave's slices of the stage the tile's last step has just released
+            gemm_epilogue_wide<WM, WN, TM, TN, GATE>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
+        else
+            gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
         ++s;
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false, bool WIDE = false>
 int launch_stream(const GemmP &p, int groups, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
     static int slots = 0;
-    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT>;
+    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE>;
     if (slots == 0) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int dev = 0, cus = 256;
@@ -390,7 +400,21 @@ int launch_stream(const GemmP &p, int groups, hipStream_t st)
     return 1;
 }
 
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false>
+int launch_stream_w(const GemmP &p, int groups, hipStream_t st)
+{
+    if (p.wide_ok && g_wide) return launch_stream<WM, WN, TM, TN, GATE, AMODE, SPLIT, true>(p, groups, st);
+    return launch_stream<WM, WN, TM, TN, GATE, AMODE, SPLIT, false>(p, groups, st);
+}
+
 }  // namespace
+
+int ldm_gemm_stream_wide(int v)
+{
+    const int old = g_wide;
+    if (v == 0 || v == 1) g_wide = v;
+    return old;
+}
 
 // Chooses a stream-kernel instance for the problem; returns 1 if it launched, 0 if the caller should
 // fall back to the tile-per-block kernel.
@@ -400,22 +424,22 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
     if (split && p.M > 128) {
         // split schedule: wave tiles of 64x64 (or 64x32 x two gate matrices) so that each split fragment feeds two
         // tiles; shapes it does not cover (grouped conv N = 32, tiny M) fall through to the exact-fp32 instances
-        if (gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS, true>(p, groups, st);
-        if (!gate && amode == LDM_A_CONV3X3 && unit % 128 == 0) return launch_stream<2, 2, 2, 2, false, LDM_A_CONV3X3, true>(p, groups, st);
-        if (!gate && amode == LDM_A_ROWS && unit % 128 == 0) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, true>(p, groups, st);
+        if (gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, true, LDM_A_ROWS, true>(p, groups, st);
+        if (!gate && amode == LDM_A_CONV3X3 && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3, true>(p, groups, st);
+        if (!gate && amode == LDM_A_ROWS && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS, true>(p, groups, st);
     }
     if (gate) {
         if (amode != LDM_A_ROWS) return 0;
-        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS>(p, groups, st);
-        return launch_stream<4, 1, 1, 1, true, LDM_A_ROWS>(p, groups, st);
+        if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, true, LDM_A_ROWS>(p, groups, st);
+        return launch_stream_w<4, 1, 1, 1, true, LDM_A_ROWS>(p, groups, st);
     }
     // 128x64 output tiles (not 128x128): 96 fewer live registers in the last-step path (no spills at two
     // workgroups per CU), twice the tiles (finer wave quantisation at the deep stages)
     if (amode == LDM_A_CONV3X3) {
-        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_CONV3X3>(p, groups, st);
-        return launch_stream<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
+        if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_CONV3X3>(p, groups, st);
+        return launch_stream_w<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
     }
-    if (p.M <= 32 && unit % 128 == 0) return launch_stream<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
-    if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
-    return launch_stream<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+    if (p.M <= 32 && unit % 128 == 0) return launch_stream_w<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+    if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
+    return launch_stream_w<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
 }

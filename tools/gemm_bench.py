@@ -63,6 +63,8 @@ def cases(B=256):
 
 if __name__ == "__main__":
     variants = [int(v) for v in sys.argv[1:]] or [0, 1]
+    if os.environ.get("GEMM_WIDE") is not None:
+        ops.gemm_wide_epilogue(int(os.environ["GEMM_WIDE"]))
     cs = cases()
     flt = os.environ.get('GEMM_CASES')
     if flt:
