@@ -1,0 +1,249 @@
+// Grouped 3x3 convolution, 32 channels in / 32 out per group (unet.py:30,44), as its own fp32-MFMA kernel.
+//
+// Through the generic stream GEMM this op is an implicit-im2col problem with N = 32: every K-step (one tap) re-fetches
+// a 128-pixel x 32-channel A tile for only 16 MFMAs per wave, i.e. 5 LDS-DMA instructions per 1024 MFMA cycles -- the
+// kernel sits at MFMA-busy 0.50, paced by DMA issue.  Here a workgroup loads, ONCE, the flattened pixel range
+// [m0 - W - 1, m0 + 128 + W + 1) of its group's 32 channels (every 3x3 neighbour of pixel m is pixel m + dy*W + dx of
+// that range) plus the group's 9 x 32 x 32 weights, then runs all nine taps out of LDS: 15 DMA instructions per
+// 9216 MFMA cycles.  Image borders are handled at fragment-read time: an invalid neighbour reads a zero row.
+//
+// Same k-order as the stream / tile GEMM kernels (tap-major, then the (quarter, e, half-wave) map of their K-steps),
+// so results are bit-identical to the generic path.
+#include "gemm_common.h"
+#include <cstdlib>
+
+using namespace ldmgemm;
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void glds16(const float *src, float *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+// LDS fragment reads as inline asm: hipcc's waitcnt pass puts "s_waitcnt vmcnt(0)" in front of every LDS read that
+// follows an LDS-DMA it cannot disambiguate -- which would wait for the NEXT tile's pixel block at the first fragment
+// of the current one.  Reads issued this way are invisible to that pass; lds_wait() is the matching explicit wait and
+// ties the fragment registers to it so that no consumer can be scheduled ahead of the wait.
+__device__ __forceinline__ f32x4 lds_read16(unsigned byte_addr)
+{
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+__device__ __forceinline__ void lds_wait(f32x4 &a, f32x4 &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+
+constexpr int NW = 8;                      // waves per workgroup: two per SIMD, so one wave's address / epilogue work
+                                           // runs under the other's MFMAs (each wave is ONE dependent MFMA chain)
+constexpr int TM = 1;                      // 32-row fragments per wave
+constexpr int BM = NW * TM * 32;           // pixels per workgroup
+
+// Persistent workgroups (one per CU): each walks a contiguous run of (group, pixel-tile) ids.  LDS: one zero row, TWO
+// pixel blocks [NPp slots][32 floats] (the next tile's block is fetched by LDS-DMA while the current one is in the
+// MFMAs -- its DMA instructions are spread over the MFMA quarters), the group's weights [9 taps][32 out][32 in]
+// (re-fetched only when the run crosses into another group); all rows 128 B, 16-byte chunks XOR-swizzled by
+// (row >> 1) & 7 like the GEMM tiles.
+__global__ __launch_bounds__(NW * 64) void gconv3x3_kernel(const GemmP p, int ntm, int total, int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int W = p.W, H = p.H;
+    const int NP = BM + 2 * W + 2;
+    const int NPp = (NP + 7) & ~7;                             // DMA instructions cover 8 slots: pad so the tail stays inside
+    const int npieces = NPp / 8;                               // DMA instructions per pixel block (all waves together)
+    float *Zs = lds, *Ab = lds + 32, *Ws = Ab + 2 * NPp * 32;
+    const int first = (int)blockIdx.x * chunk;
+    const int last = first + chunk < total ? first + chunk : total;
+    if (first >= last) return;
+
+    // one DMA instruction of a pixel block: piece k covers slots [8k, 8k + 8)
+    auto a_piece = [&](int id, int k, float *dst) {
+        const int g = id / ntm, m0 = (id - g * ntm) * BM;
+        const int slot = 8 * k + (lane >> 3), cpos = lane & 7;
+        int m = m0 - W - 1 + slot;
+        m = m < 0 ? 0 : (m < p.M ? m : p.M - 1);
+        glds16(p.a + g * p.a_gstride + (long long)m * p.lda + ((cpos ^ ((slot >> 1) & 7)) << 2), dst + k * 256);
+    };
+    auto w_load = [&](int g) {
+        const float *wbase = p.w[0] + g * p.w_gstride;
+        for (int q0 = wave * 64; q0 < 9 * 32 * 8; q0 += NW * 64) {    // 2304 chunks: exact multiple of 64
+            const int q = q0 + lane;
+            const int row = q >> 3, cpos = q & 7;                  // row = tap * 32 + n
+            const int tap = row >> 5, n = row & 31;
+            glds16(wbase + (long long)n * p.ldw + tap * 32 + ((cpos ^ ((row >> 1) & 7)) << 2), Ws + q0 * 4);
+        }
+    };
+
+    if (t < 8) *(f32x4 *)(Zs + t * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur_g = first / ntm;
+    w_load(cur_g);
+    for (int k = wave; k < npieces; k += NW) a_piece(first, k, Ab);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int wsw = (r >> 1) & 7;                              // ((tap * 32 + r) >> 1) & 7
+    int woff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = r * 32 + (((2 * j + h) ^ wsw) << 2);
+
+#pragma unroll 1
+    for (int id = first; id < last; ++id) {
+        const int g = id / ntm, m0 = (id - g * ntm) * BM;
+        const float *As = Ab + ((id - first) & 1) * NPp * 32;
+        float *An = Ab + ((id - first + 1) & 1) * NPp * 32;
+        if (g != cur_g) {                                      // the run crossed into another group: everyone is past its W reads
+            cur_g = g;
+            w_load(g);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+
+        if (id + 1 < last)                                     // next tile's pixel block: lands under this tile's MFMAs
+            for (int k = wave; k < npieces; k += NW) a_piece(id + 1, k, An);
+
+        // ---- this lane's pixels (one per fragment): LDS row and swizzle of each of their nine neighbours ---------
+        int aoff[TM][9], asw[TM][9];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wave * TM + i) * 32 + r;
+            const int x = m % W, y = (m / W) % H;
+            const bool live = m < p.M;
+            const int slot0 = (wave * TM + i) * 32 + r + W + 1;    // the pixel's own slot
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool ok = live && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+                const int slot = ok ? slot0 + dy * W + dx : -1;    // outside the image: the zero row (in front of the blocks)
+                aoff[i][tap] = ok ? (int)(As - lds) + slot * 32 : 0;
+                asw[i][tap] = ok ? (slot >> 1) & 7 : 0;
+            }
+        }
+
+        // bias / addend of the epilogue: issued now, consumed after the MFMAs (rows past M are clamped, never stored)
+        const int col = g * (int)p.o_gstride + r;
+        const float bias = *(p.bias[0] ? p.bias[0] + g * p.b_gstride + r : ldm_zero_block);
+        const int row_first = m0 + wave * TM * 32 + 4 * h;
+        const bool full = m0 + BM <= p.M;
+        const int rclamp = row_first < p.M ? row_first : p.M - 1;
+        const float *abase_e = p.addend ? p.addend + (long long)rclamp * p.ldadd + col : ldm_zero_block;
+        const int lda_e = p.addend ? (int)p.ldadd : 0;
+        float pre[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int roff = i * 32 + (e & 3) + 8 * (e >> 2);
+                if (!full) roff = row_first + roff < p.M ? roff : (p.M - 1 - rclamp);
+                pre[i][e] = abase_e[roff * lda_e];
+            }
+
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        // Fragments are fetched one quarter of a tap ahead of their use; each accumulator is ONE dependent MFMA chain in
+        // the generic GEMM's k-order, the two chains of a wave interleave.  sched_barrier keeps hipcc from sinking the
+        // LDS reads behind the MFMA group that is meant to cover their latency.
+        const unsigned ws_addr = (unsigned)(size_t)(lptr_t)Ws, lds_addr = (unsigned)(size_t)(lptr_t)lds;
+        auto frag = [&](int idx, f32x4 (&af)[TM], f32x4 &bf) {
+            const int tap = idx >> 2, j = idx & 3;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds_read16(lds_addr + 4u * (unsigned)(aoff[i][tap] + (((2 * j + h) ^ asw[i][tap]) << 2)));
+            bf = lds_read16(ws_addr + 4u * (unsigned)(tap * 1024 + woff[j]));
+        };
+        auto mma = [&](const f32x4 (&af)[TM], const f32x4 &bf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+        };
+        static_assert(TM == 1, "lds_wait ties exactly one A fragment and one W fragment");
+        f32x4 a0[TM], a1[TM], b0, b1;
+        frag(0, a0, b0);
+#pragma unroll
+        for (int idx = 0; idx < 36; idx += 2) {
+            lds_wait(a0[0], b0);                       // fragments of quarter idx (issued one MFMA group ago)
+            frag(idx + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);                // reads stay in front of the MFMA group that hides them
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait(a1[0], b1);
+            if (idx + 2 < 36) frag(idx + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // the next block has landed for this wave and this wave is done reading the current one; after the barrier that
+        // holds for all waves.  Placed BEFORE the epilogue so that its stores drain under the next tile's MFMAs.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- epilogue (MFMA C/D map: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h) -----------------------
+        float *obase = p.out + (long long)row_first * p.ldo + col;
+        const int ldo_e = (int)p.ldo;
+        const float slope = p.act == LDM_ACT_LRELU ? p.slope : 1.f;
+        const bool relu = p.act == LDM_ACT_RELU, has_add = p.addend != nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int roff = i * 32 + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][e] + bias;
+                const float vr = fmaxf(v, 0.f), vl = v > 0.f ? v : v * slope;
+                v = relu ? vr : vl;
+                if (has_add) v += pre[i][e];
+                acc[i][e] = v;
+            }
+        if (full) {                                            // whole tile inside M: no per-row predicate
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) obase[(i * 32 + (e & 3) + 8 * (e >> 2)) * ldo_e] = acc[i][e];
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int roff = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (row_first + roff < p.M) obase[roff * ldo_e] = acc[i][e];
+                }
+        }
+    }
+}
+
+}  // namespace
+
+// Returns 1 if the problem is a 32-in / 32-out-per-group 3x3 convolution this kernel covers (and launches it), else 0.
+int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipStream_t st)
+{
+    if (gate || amode != LDM_A_CONV3X3 || groups < 2 || p.N != 32 || p.Cin != 32 || p.K != 288) return 0;
+    if (p.o_mode != LDM_O_ROWS || p.use_table || p.nseg != 1 || p.a_gstride != 32 || p.W > 64) return 0;
+    if (p.lda > 0x7fffff || p.ldo > 0x7fffff || p.o_gstride > 0x7fffff) return 0;
+    const int ntm = (p.M + BM - 1) / BM;
+    const long long total = (long long)ntm * groups;
+    if (total > 0x3fffffffLL) return 0;
+    const int NPp = (BM + 2 * p.W + 2 + 7) & ~7;
+    const size_t smem = ((size_t)32 + 2 * (size_t)NPp * 32 + 9 * 32 * 32) * sizeof(float);
+    static int cus = 0;
+    if (cus == 0) {
+        (void)hipFuncSetAttribute((const void *)gconv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        int dev = 0;
+        cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const int wgs = (int)(total < cus ? total : cus);
+    const int chunk = (int)((total + wgs - 1) / wgs);
+    hipLaunchKernelGGL(gconv3x3_kernel, dim3((unsigned)((total + chunk - 1) / chunk)), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
+    return 1;
+}

@@ -210,11 +210,13 @@ int g_variant = 1;      // 0: tile-per-block kernel, 1: persistent LDS-DMA strea
 }  // namespace
 
 int ldm_gemm_stream_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st, bool split);
+int ldm_gconv3x3_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st);
 
 namespace {
 
 void launch_any(const GemmP &p, int groups, bool gate, int a_mode, hipStream_t st)
 {
+    if (g_variant >= 1 && ldm_gconv3x3_dispatch(p, groups, gate, a_mode, st)) return;
     if (g_variant >= 1 && ldm_gemm_stream_dispatch(p, groups, gate, a_mode, st, g_variant == 2)) return;
     if (gate)
         dispatch<true, LDM_A_ROWS>(p, groups, st);

@@ -106,6 +106,35 @@ def test_grouped_conv3x3(ops, gpu_device, B, H, W, C):
     assert rel_l2(got, ref) < KTOL
 
 
+def test_grouped_conv3x3_dedicated_kernel_bit_identical(gpu_device):
+    """The stream schedule routes 32-per-group 3x3 convolutions to their own kernel (gconv.hip: pixel block + weights
+    resident in LDS, borders as zero-row reads); the tile schedule keeps the generic implicit-im2col GEMM.  Same
+    k-order -> bitwise equal, on ragged tiles, several images per tile, wide and tiny maps, with and without addend."""
+    from ldm_image_generator_amd import ops as o
+    for (B, H, W, C, act, with_add) in [(3, 32, 32, 128, o.ACT_NONE, True), (5, 7, 5, 64, o.ACT_RELU, True),
+                                        (70, 4, 4, 256, o.ACT_NONE, False), (2, 12, 64, 64, o.ACT_LRELU, True),
+                                        (1, 40, 96, 64, o.ACT_NONE, True)]:
+        M = B * H * W
+        rows = rnd(M, C).cuda()
+        add = rnd(M, C, seed=3).cuda() if with_add else None
+        wp = rnd(C, 288, seed=1, scale=288 ** -0.5).cuda()
+        b = rnd(C, seed=2).cuda()
+        outs = []
+        for v in (0, 1):
+            old = o.gemm_variant(v)
+            out = torch.zeros(M, C, device=gpu_device)
+            o.gemm(rows, M, 32, 288, [wp], out, lda=C, ldw=288, biases=[b], addend=add, ldadd=C, ldo=C, act=act, slope=0.01,
+                   a_mode=o.A_CONV3X3, conv_hw=(H, W), cin=32, groups=C // 32, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
+            outs.append(out)
+            o.gemm_variant(old)
+        assert torch.equal(outs[0], outs[1]), (B, H, W, C)
+        xn = rows.cpu().double().reshape(B, H, W, C).permute(0, 3, 1, 2)
+        ref = F.conv2d(xn, wp.cpu().double().reshape(C, 3, 3, 32).permute(0, 3, 1, 2), b.cpu().double(), padding=1, groups=C // 32)
+        ref = F.relu(ref) if act == o.ACT_RELU else (F.leaky_relu(ref, 0.01) if act == o.ACT_LRELU else ref)
+        ref = ref.permute(0, 2, 3, 1).reshape(M, C) + (add.cpu().double() if with_add else 0)
+        assert rel_l2(outs[1].cpu().double(), ref) < KTOL, (B, H, W, C)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 3, 5, 64, 32), (1, 8, 8, 128, 64)])
 def test_conv_transpose_2x2(ops, gpu_device, B, H, W, Cin, Cout):
     x = rnd(B, Cin, H, W)
