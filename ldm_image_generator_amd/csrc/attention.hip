@@ -156,6 +156,166 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const AttnP p)
     for (int c = 0; c < 8; ++c) *(f32x4 *)(orow + 4 * c) = f32x4{o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]};
 }
 
+// ---- MFMA version (L <= 48 tokens: every window the reference ever builds) -----------------------------------------
+// One wave per (sample, window, head); v_mfma_f32_16x16x4_f32 (exact fp32) for both products.
+//   S^T = K Q^T   tiles [key tile][query tile]: the A operand is K, the B operand is Q; a lane (c = lane & 15,
+//                 g = lane >> 4) reads row c of the tile straight from global memory, dims [8g, 8g + 8) (the contraction
+//                 order is a free permutation as long as both operands use the same one).
+//   softmax       the C/D map leaves a lane with ONE query column (c) and the keys {16 kt + 4 g + e}: the row
+//                 reductions are 12 values in registers plus two cross-lane steps (xor 16, xor 32).
+//   O^T = V^T P^T P^T is the B operand and is ALREADY in registers in the right place (k = key 16 kt + 4 g + e on lane
+//                 group g, column = query c); V^T comes from an LDS image of V (rows = keys, stride 36 floats:
+//                 conflict-free); the result leaves as 16-byte stores (query c, dims [16 dt + 4 g, + 4)).
+template <int NT>
+__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const AttnP p)
+{
+    constexpr int RS = 36, LT = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int L = p.L, C = p.C;
+    float *Vs = smem + wave * (LT * RS + LT);
+    float *Kb = Vs + LT * RS;                 // additive key bias (0, -inf, or the float "mask"); -inf past L
+
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const bool active = gw < p.total_waves;
+    const int head = (int)(gw % p.heads);
+    const long long t1 = gw / p.heads;
+    const int nwin = p.global ? 1 : p.nwh * p.nww;
+    const int win = (int)(t1 % nwin);
+    const long long b = t1 / nwin;
+    const int wr = win / p.nww, wc = win - wr * p.nww;
+    const long long img = b * p.H * p.W;
+    const float scale = 0.17677669529663687f;        // sqrt(1/32), applied to q (torch F.multi_head_attention_forward)
+
+    f32x4 kf[NT][2], qf[NT][2];
+    long long orow[NT];
+    bool qok[NT];
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + c;
+            int sy = 0, sx = 0, py, px;
+            const bool ok = j < L && token_src(p, wr, wc, j, sy, sx, py, px);
+            // zero-padded token: the projection of 0 is the bias (attention.py:27-28); tokens past L only need finite values
+            const float *row = ok ? p.qkv + (img + (long long)sy * p.W + sx) * 3 * C + head * 32 : p.bias + head * 32;
+            qok[t] = ok;
+            orow[t] = (img + (long long)sy * p.W + sx) * C + head * 32;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 qv = *(const f32x4 *)(row + 8 * g + 4 * u);
+                kf[t][u] = *(const f32x4 *)(row + C + 8 * g + 4 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[t][u][e] = __fmul_rn(qv[e], scale);
+            }
+        }
+        for (int idx = lane; idx < LT * 8; idx += 64) {
+            const int j = idx >> 3, ch = (idx & 7) * 4;
+            int sy, sx, py, px;
+            f32x4 vv{0.f, 0.f, 0.f, 0.f};
+            if (j < L) {
+                const bool ok = token_src(p, wr, wc, j, sy, sx, py, px);
+                vv = ok ? *(const f32x4 *)(p.qkv + (img + (long long)sy * p.W + sx) * 3 * C + 2 * C + head * 32 + ch)
+                        : *(const f32x4 *)(p.bias + 2 * C + head * 32 + ch);
+            }
+            *(f32x4 *)(Vs + j * RS + ch) = vv;
+        }
+        if (lane < LT) {
+            float kb = -INFINITY;
+            if (lane < L) {
+                int sy, sx, py, px;
+                const bool ok = token_src(p, wr, wc, lane, sy, sx, py, px);
+                kb = 0.f;
+                if (!p.global) {
+                    if (p.shift == 0) {
+                        kb = ok ? 0.f : -INFINITY;              // bool key_padding_mask (attention.py:31-35)
+                    } else {
+                        // attention.py:40: "mask" = roll(roll(x_pad)) channel 0, a float added to the logits
+                        int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
+                        my += my < 0 ? p.Hp : 0;
+                        mx += mx < 0 ? p.Wp : 0;
+                        kb = (my < p.H && mx < p.W) ? p.xf[(img + (long long)my * p.W + mx) * C] : 0.f;
+                    }
+                }
+            }
+            Kb[lane] = kb;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // ---- S^T = K Q^T --------------------------------------------------------------------------------------------
+    f32x4 s[NT][NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt)
+                s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][st >> 2][st & 3], qf[qt][st >> 2][st & 3], s[kt][qt], 0, 0, 0);
+
+    // ---- softmax over the keys of each query column ------------------------------------------------------------
+    float kbv[NT][4];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kbv[kt][e] = Kb[16 * kt + 4 * g + e];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[kt][qt][e] += kbv[kt][e];
+                mx = fmaxf(mx, s[kt][qt][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[kt][qt][e] = expf(s[kt][qt][e] - mx);
+                sum += s[kt][qt][e];
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kt][qt][e] *= inv;
+    }
+
+    // ---- O^T = V^T P^T ------------------------------------------------------------------------------------------
+    f32x4 o[NT][2];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) o[qt][0] = o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float vt = Vs[(16 * kt + 4 * g + e) * RS + 16 * dt + c];
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt, s[kt][qt][e], o[qt][dt], 0, 0, 0);
+            }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+        if (qok[qt]) {                          // padded queries are cropped (attention.py:59)
+            float *dst = p.out + orow[qt] + 4 * g;
+            *(f32x4 *)dst = o[qt][0];
+            *(f32x4 *)(dst + 16) = o[qt][1];
+        }
+}
+
 }  // namespace
 
 extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_bias, const float *xf, float *out, int B, int H,
@@ -182,9 +342,12 @@ extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_b
     p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
     const unsigned blocks = (unsigned)((p.total_waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (p.L <= 36) {
-        const size_t smem = 4ull * (2 * 36 * 32 + 36) * sizeof(float);
-        hipLaunchKernelGGL(window_attention_kernel<36>, dim3(blocks), dim3(256), smem, st, p);
+    if (p.L <= 16) {
+        hipLaunchKernelGGL(window_attention_mfma_kernel<1>, dim3(blocks), dim3(256), 4ull * (16 * 36 + 16) * sizeof(float), st, p);
+    } else if (p.L <= 32) {
+        hipLaunchKernelGGL(window_attention_mfma_kernel<2>, dim3(blocks), dim3(256), 4ull * (32 * 36 + 32) * sizeof(float), st, p);
+    } else if (p.L <= 48) {
+        hipLaunchKernelGGL(window_attention_mfma_kernel<3>, dim3(blocks), dim3(256), 4ull * (48 * 36 + 48) * sizeof(float), st, p);
     } else {
         const size_t smem = 4ull * (2 * 64 * 32 + 64) * sizeof(float);
         static bool attr_done = false;
