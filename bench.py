@@ -156,7 +156,7 @@ def main():
             "denoise_steps_per_sec": images * T / dt / B, "sample_steps_per_sec": images * T / dt,
             "algorithmic_tflops": algo_flops / dt / 1e12 if args.mode == "eval" else None,
             "outputs_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all launches of the timed region",
+            "roofline": {"bound": "mfma", "kernel": "ldm_gemm_f32 family (gemm_stream_kernel, gconv3x3_kernel; v_mfma_f32_32x32x2_f32), all launches of the timed region",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": launches, "kernel_ms": gemm_ms, "gflop_per_sample_step_measured":

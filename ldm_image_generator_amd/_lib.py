@@ -144,6 +144,9 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    v = os.environ.get("LDM_GEMM_VARIANT")            # opt-in GEMM schedule for a whole process (see ldm_gemm_variant)
+    if v is not None:
+        lib.ldm_gemm_variant(int(v))
     return lib
 
 

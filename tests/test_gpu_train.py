@@ -120,7 +120,7 @@ def test_training_step_matches_reference_gradients(gpu_device):
     e_theta = net(x=xt, time=t.cuda(), condition=None)
     loss = L1LossFunction.apply(e_theta, e)
     loss.backward()
-    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
     names = [str(n) for n in g["grad_names"]]
     norms = dict(zip(names, g["grad_norms"]))
     worst = 0.0

@@ -17,7 +17,15 @@ SIMDS = 256 * 4
 
 def short_name(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name[name.find("gemm"):].split("(")[0] if "gemm" in name else name.split("(")[0].split("<")[0][-48:]
+    for k in ("gemm_stream_kernel", "gemm_f32_kernel"):
+        if k in name:
+            return name[name.find(k):].split("(")[0]
+    return name.split("(")[0].split("<")[0][-48:]
+
+
+def in_gemm_family(key):
+    """Kernels launched by ldm_gemm_f32 (the roofline's "dominant kernel" family)."""
+    return key.startswith("gemm_") or key.startswith("gconv3x3") or key.startswith("splitk")
 
 
 def main(pmc_dir, tag):
@@ -48,7 +56,7 @@ def main(pmc_dir, tag):
             busy = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * cyc) if cyc else 0.0
             out.write("| `%s` | %d | %.1f | %.3f | %.2f | %.1f %% |\n" % (key[:64], a["n"], a["ns"] / a["n"] / 1e3, busy,
                                                                       cyc / max(a["ns"], 1), 100.0 * a["ns"] / all_ns))
-            if "gemm" in key:
+            if in_gemm_family(key):
                 for k in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "ns"):
                     tot[k] += a.get(k, 0.0)
         cyc = tot["GRBM_GUI_ACTIVE"] / 8.0

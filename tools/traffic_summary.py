@@ -12,7 +12,15 @@ import sys
 
 def short_name(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name[name.find("gemm"):].split("(")[0] if "gemm" in name else name.split("(")[0].split("<")[0][-48:]
+    for k in ("gemm_stream_kernel", "gemm_f32_kernel"):
+        if k in name:
+            return name[name.find(k):].split("(")[0]
+    return name.split("(")[0].split("<")[0][-48:]
+
+
+def in_gemm_family(key):
+    """Kernels launched by ldm_gemm_f32 (the roofline's "dominant kernel" family)."""
+    return key.startswith("gemm_") or key.startswith("gconv3x3") or key.startswith("splitk")
 
 
 def per_kernel(pattern, counter):
@@ -40,7 +48,7 @@ if __name__ == "__main__":
         wb = W.get(k, [1, 0.0, 0.0])[1]
         rows.append(dict(kernel=k, launches=n, fetch_bytes_x2_per_launch=2 * fb / n, write_bytes_per_launch=wb / n,
                          avg_us=ns / n / 1e3))
-        if "gemm" in k:
+        if in_gemm_family(k):
             tot[0] += n
             tot[1] += 2 * fb + wb
             tot[2] += ns

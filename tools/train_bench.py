@@ -16,8 +16,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--latent", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--gemm-variant", type=int, default=1, help="1 = exact-fp32 stream schedule, 2 = bf16x3 split consumer")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+ops.gemm_variant(args.gemm_variant)
 net = UNet()
 net.load_state_dict(synth.fill_state_dict(net.state_dict()))
 net = net.to(dev).train()
