@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--num-steps", type=int, default=50, help="DDIM steps per image")
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
                     help="eval: all 36 blocks run (headline, FLOPs deterministic); train: the reference's stochastic depth")
+    ap.add_argument("--gather", default="f32", choices=["f32", "u8"],
+                    help="what the single all-gather moves: the fp32 images SURVEY 8(d) defines the metric on (default), or the "
+                         "device-side uint8 HWC post-process of sample_ldm.py:75-77 (a quarter of the bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the secondary measurement under GEMM schedule 2 (bf16x3 split consumer)")
@@ -68,7 +71,7 @@ def main():
     from ldm_image_generator_amd import ops, synth
     from ldm_image_generator_amd.ddpm import DDPM
     from ldm_image_generator_amd.unet import UNet
-    from ldm_image_generator_amd.vae import Decoder
+    from ldm_image_generator_amd.vae import Decoder, to_uint8_images
     import torch.distributed as dist
 
     rank, world, local = ldist.init_from_env()
@@ -94,6 +97,8 @@ def main():
     def one_pass(seed):
         z = ddpm.sample((B, 8, 32, 32), seed=seed, num_steps=T, x_init=x_t, progress=False)
         img = dec(z)
+        if args.gather == "u8":
+            img = to_uint8_images(img)
         return ldist.gather_images(img, gb, rank, world)
 
     def fence():
@@ -121,7 +126,7 @@ def main():
         return float(t_max.item()), prof, out
 
     dt, (launches, gemm_ms, gemm_flops), out = measure(args.warmup, args.steps)
-    finite = bool(torch.isfinite(out).all().item())
+    finite = bool(torch.isfinite(out.float()).all().item())
 
     # secondary leg, never the headline: the same passes under GEMM schedule 2 (fp32 operands cut exactly into three
     # bf16 pieces, six bf16 MFMAs per product, fp32 accumulate -- DESIGN.md 3.1), with its deviation from the
@@ -152,7 +157,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "sample_ldm 256x256, %d DDIM steps, batch %d per GPU: UNet(385.7M) + VAE Decoder, "
                                    "formula weights, %s-mode" % (T, B, args.mode),
-                       "global_batch": gb, "latent": [8, 32, 32], "parallelism": "dp%d" % world},
+                       "global_batch": gb, "latent": [8, 32, 32], "parallelism": "dp%d" % world, "gathered": args.gather},
             "denoise_steps_per_sec": images * T / dt / B, "sample_steps_per_sec": images * T / dt,
             "algorithmic_tflops": algo_flops / dt / 1e12 if args.mode == "eval" else None,
             "outputs_finite": finite,

@@ -64,15 +64,21 @@ def gather_images(local_images, global_batch, rank, world):
     return torch.cat(parts, dim=0)
 
 
-def sample_images_sharded(sample_fn, decode_fn, global_batch, latent_shape, seed, rank, world, device, gather=True):
+def sample_images_sharded(sample_fn, decode_fn, global_batch, latent_shape, seed, rank, world, device, gather=True,
+                          as_uint8=False):
     """Run ``decode_fn(sample_fn(x_T_slice))`` on this rank's slice and all-gather the images.
 
     sample_fn(x_T [b, ...] on device) -> latents; decode_fn(latents) -> images.  Every
-    rank must call with the same (global_batch, latent_shape, seed).
+    rank must call with the same (global_batch, latent_shape, seed).  ``as_uint8`` applies the reference's
+    post-process (sample_ldm.py:75-77: clamp, scale, truncate, HWC) on the device BEFORE the gather, so the one
+    collective moves [B, H, W, 3] uint8 -- a quarter of the fp32 message.
     """
     lo, hi = shard_bounds(global_batch, rank, world)
     x_t = global_noise(global_batch, latent_shape, seed)[lo:hi].to(device)
     images = decode_fn(sample_fn(x_t))
+    if as_uint8:
+        from .vae import to_uint8_images
+        images = to_uint8_images(images)
     return gather_images(images, global_batch, rank, world) if gather else images
 
 

@@ -275,6 +275,20 @@ def test_cfg2_pixel_space_geometry_full_width(gpu_device):
     assert rel_l2(x0, ref0) < 1e-4 and max_rel(x0, ref0) < 1e-3
 
 
+def test_sharded_sampling_uint8_postprocess_before_gather(gpu_device):
+    """the device-side clamp / scale / truncate / HWC of sample_ldm.py:75-77 composes with the sharded driver."""
+    from ldm_image_generator_amd import dist as ld
+    from ldm_image_generator_amd.vae import Decoder, to_uint8_images
+    dec = formula(Decoder(channels=[64, 32, 32], stages=[1, 2, 1]))
+    with torch.no_grad():
+        f32 = ld.sample_images_sharded(lambda x: x * 0.5, dec, 3, (8, 6, 5), 7, 0, 1, gpu_device)
+        u8 = ld.sample_images_sharded(lambda x: x * 0.5, dec, 3, (8, 6, 5), 7, 0, 1, gpu_device, as_uint8=True)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, f32.shape[2], f32.shape[3], 3)
+    ref = (torch.clamp(f32.cpu(), -1, 1).numpy() * 127.5 + 127.5).astype(np.uint8).transpose(0, 2, 3, 1)
+    assert np.array_equal(u8.cpu().numpy(), ref)
+    assert torch.equal(u8, to_uint8_images(f32))
+
+
 def test_sample_schedule_list_eta_and_errors(tiny_unet):
     """ddpm.py:68-71 (explicit schedule list, unknown schedule -> TypeError) and eta > 0 (sigma * e term) with injected noise."""
     from ldm_image_generator_amd import synth
