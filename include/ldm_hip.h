@@ -234,6 +234,13 @@ int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulat
 /* out[Cc, R] = x[R, Cc]^T and csum[c] = sum_r x[r][c] in one pass (activation transpose + bias gradient) */
 int ldm_transpose_colsum_f32(const float *x, float *out, float *csum, long long R, int Cc, void *stream);
 int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream);        /* split-K sum */
+/* Weight gradient of a 1x1 conv / Linear WITHOUT transposed copies (autograd of modules.py:10-12, unet.py:20-21,
+ * attention in/out projections): out[s][n][k] = sum over rows m of split s of a[m*lda + n] * b[m*ldb + k], i.e.
+ * dW = dY^T X with the pixel rows as the contraction.  N, K multiples of 128; M / splits a multiple of 32; the caller
+ * sums the `splits` partial planes (ldm_reduce_partials_f32) -- fixed order, deterministic.  colsum_a (optional,
+ * [splits][N]) receives the column sums of `a` per split: the bias gradient that goes with dW. */
+int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, long long ldb, float *out, float *colsum_a, int M, int N, int K,
+                    int splits, void *stream);
 /* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) += per (slot, pixel) (atomic) */
 int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, const int *slot, const float *dxf, const float *dres,
                                  float *dx, float *dfilm, int B, int HW, int C, float eps, void *stream);

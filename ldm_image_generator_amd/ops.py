@@ -15,7 +15,7 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
            "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
-           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue",
+           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue", "gemm_tn",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
 
@@ -253,6 +253,14 @@ def colsum(x, M, N, out=None, accumulate=False):
 def transpose_colsum(x, out, csum):
     r, c = x.shape
     _call("ldm_transpose_colsum_f32", _dev(x, "x"), _dev(out, "out"), _dev(csum, "csum"), r, c)
+
+
+def gemm_tn(a, b, out, M, N, K, splits=1, lda=None, ldb=None, colsum=None):
+    """out[s] [N, K] = sum over the rows of split s of a[m, :N]^T b[m, :K] (weight gradients, no transposed copies);
+    ``colsum`` [splits, N] optionally receives the per-split column sums of ``a`` (the bias gradient)."""
+    _call("ldm_gemm_tn_f32", _dev(a, "a"), N if lda is None else lda, _dev(b, "b"), K if ldb is None else ldb, _dev(out, "out"),
+          _opt(colsum, "colsum"), M, N, K, splits)
+    return out
 
 
 def reduce_partials(parts, S, n, out):

@@ -83,6 +83,63 @@ def grad_weight(dy_t, x_t, m_red):
     return ops.reduce_partials(parts, s, n_out * k_out, out)
 
 
+class _Rows:
+    """A row-major [M, N] activation / gradient whose transpose and column sums are produced on demand, once."""
+
+    def __init__(self, x):
+        self.x = x
+        self._t = None
+        self._cs = None
+
+    def t(self):
+        if self._t is None:
+            if self._cs is None:
+                self._t, self._cs = _T_colsum(self.x)
+            else:
+                self._t = _T(self.x)
+        return self._t
+
+    def colsum(self):
+        if self._cs is None:
+            if self._t is None:
+                self._cs = ops.colsum(self.x, self.x.shape[0], self.x.shape[1])
+            else:                                   # cannot happen with the call order below; kept for completeness
+                self._t, self._cs = _T_colsum(self.x)
+        return self._cs
+
+
+def _tn_splits(n_out, k_out, m_red):
+    tiles = (n_out // 128) * (k_out // 128)
+    s = 1
+    while tiles * s < 512 and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 32 == 0 and m_red // (2 * s) >= 256 and s < 256:
+        s *= 2
+    return s
+
+
+def grad_weight_rows(dy, x, m_red):
+    """dW [N, K] = dy^T x for row-major dy [M, N], x [M, K] (``_Rows``).  Wide layers go through the TN kernel with
+    the operands as they lie in memory; narrow ones (tiny test nets) fall back to explicit transposes + the NT GEMM."""
+    n_out, k_out = dy.x.shape[1], x.x.shape[1]
+    if m_red % 32:
+        raise ValueError("training path needs the number of rows (%d) to be a multiple of 32" % m_red)
+    if n_out % 128 or k_out % 128:
+        return grad_weight(dy.t(), x.t(), m_red)
+    s = _tn_splits(n_out, k_out, m_red)
+    dev = dy.x.device
+    out = torch.empty(n_out, k_out, device=dev, dtype=torch.float32)
+    want_cs = dy._cs is None                                    # the bias gradient comes along for free
+    cs = torch.empty(s, n_out, device=dev, dtype=torch.float32) if want_cs else None
+    if s == 1:
+        ops.gemm_tn(dy.x, x.x, out, m_red, n_out, k_out, 1, colsum=cs)
+    else:
+        parts = torch.empty(s, n_out, k_out, device=dev, dtype=torch.float32)
+        ops.gemm_tn(dy.x, x.x, parts, m_red, n_out, k_out, s, colsum=cs)
+        ops.reduce_partials(parts, s, n_out * k_out, out)
+    if want_cs:
+        dy._cs = cs[0] if s == 1 else ops.reduce_partials(cs, s, n_out, torch.empty(n_out, device=dev, dtype=torch.float32))
+    return out
+
+
 class Grads:
     """parameter -> gradient accumulator for one backward."""
 
@@ -142,10 +199,10 @@ def block_backward(sv, dy, ctx, grads):
     dev = x.device
     regs = sv["regs"]
     f = regs[0].a.weight.shape[0]
-    dy_t, bias_dy = _T_colsum(dy)
-    xf_t = _T(xf)
+    dy_r, xf_r = _Rows(dy), _Rows(xf)
+    dy_t, bias_dy = dy_r.t(), dy_r.colsum()                        # the grouped conv's weight gradient needs dy^T anyway
     # ---- RandomMoE: y += sum_e c_e(a_e(xf) * relu(b_e(xf))) ----------------------------------------------
-    dwc = grad_weight(dy_t, _T(sv["hid"]), m)                       # [C, 3F]
+    dwc = grad_weight_rows(dy_r, _Rows(sv["hid"]), m)               # [C, 3F]
     dhid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
     ops.gemm(dy, m, 3 * f, c, [WT.get(_w2d(r.c.weight), r.c.weight) for r in regs], dhid)
     da = torch.empty_like(dhid)
@@ -154,10 +211,10 @@ def block_backward(sv, dy, ctx, grads):
     dxf = torch.empty(m, c, device=dev, dtype=torch.float32)
     ops.gemm(da, m, c, 3 * f, [WT.get(_w2d(r.a.weight), r.a.weight) for r in regs], dxf, seg_mode=ops.SEG_K)
     ops.gemm(db, m, c, 3 * f, [WT.get(_w2d(r.b.weight), r.b.weight) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)
-    da_t, dba = _T_colsum(da)
-    db_t, dbb = _T_colsum(db)
-    dwa = grad_weight(da_t, xf_t, m)                                # [3F, C]
-    dwb = grad_weight(db_t, xf_t, m)
+    da_r, db_r = _Rows(da), _Rows(db)
+    dwa = grad_weight_rows(da_r, xf_r, m)                           # [3F, C]
+    dwb = grad_weight_rows(db_r, xf_r, m)
+    dba, dbb = da_r.colsum(), db_r.colsum()
     for e, r in enumerate(regs):
         grads.add(r.c.weight, dwc[:, e * f:(e + 1) * f])
         grads.add(r.c.bias, bias_dy.clone())
@@ -170,16 +227,16 @@ def block_backward(sv, dy, ctx, grads):
         att = blk.self_attention.attention
         dctx = torch.empty(m, c, device=dev, dtype=torch.float32)
         ops.gemm(dy, m, c, c, [WT.get(att.out_proj.weight.detach(), att.out_proj.weight)], dctx)
-        grads.add(att.out_proj.weight, grad_weight(dy_t, _T(sv["actx"]), m))
+        grads.add(att.out_proj.weight, grad_weight_rows(dy_r, _Rows(sv["actx"]), m))
         grads.add(att.out_proj.bias, bias_dy.clone())
         dqkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
         dpad = torch.empty(3 * c, device=dev, dtype=torch.float32)
         ops.window_attention_bwd(sv["qkv"], att.in_proj_bias.detach(), xf, dctx, dqkv, dpad, b, h, w, c,
                                  blk.self_attention.window_size, blk.self_attention.shift)
         ops.gemm(dqkv, m, c, 3 * c, [WT.get(att.in_proj_weight.detach(), att.in_proj_weight)], dxf, addend=dxf)
-        dqkv_t, dbin = _T_colsum(dqkv)
-        grads.add(att.in_proj_weight, grad_weight(dqkv_t, xf_t, m))
-        grads.add(att.in_proj_bias, ops.add_(dbin, dpad))
+        dqkv_r = _Rows(dqkv)
+        grads.add(att.in_proj_weight, grad_weight_rows(dqkv_r, xf_r, m))
+        grads.add(att.in_proj_bias, ops.add_(dqkv_r.colsum().clone(), dpad))
     # ---- grouped 3x3 conv ------------------------------------------------------------------------------
     g = c // 32
     wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
@@ -222,15 +279,15 @@ def encodings_backward(enc, codes, hid, dfilm, grads):
             out[:m] = t
             return out
         codes, hid, dfilm = pad(codes), pad(hid), pad(dfilm)
-    dfilm_t, db2 = _T_colsum(dfilm)
-    grads.add(enc.proj2.weight, grad_weight(dfilm_t, _T(hid), mp))
-    grads.add(enc.proj2.bias, db2)
+    dfilm_r = _Rows(dfilm)
+    grads.add(enc.proj2.weight, grad_weight_rows(dfilm_r, _Rows(hid), mp))
+    grads.add(enc.proj2.bias, dfilm_r.colsum())
     dh = torch.empty(mp, 4 * c, device=codes.device, dtype=torch.float32)
     ops.gemm(dfilm, mp, 4 * c, 2 * c, [WT.get(_w2d(enc.proj2.weight), enc.proj2.weight)], dh)
     ops.relu_bwd(dh, hid, dh)
-    dh_t, db1 = _T_colsum(dh)
-    grads.add(enc.proj1.weight, grad_weight(dh_t, _T(codes), mp))
-    grads.add(enc.proj1.bias, db1)
+    dh_r = _Rows(dh)
+    grads.add(enc.proj1.weight, grad_weight_rows(dh_r, _Rows(codes), mp))
+    grads.add(enc.proj1.bias, dh_r.colsum())
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -320,17 +377,17 @@ class UNetFunction(torch.autograd.Function):
                 dlo = torch.empty(bb * lh * lw, cn, device=dev, dtype=torch.float32)
                 ops.sumpool2(drows, dlo, bb, 2 * lh, 2 * lw, cn)
                 mlo = bb * lh * lw
-                dlo_t, dbl2 = _T_colsum(dlo)
-                grads.add(conv.weight, grad_weight(dlo_t, _T(lo), mlo))
-                grads.add(conv.bias, dbl2)
+                dlo_r = _Rows(dlo)
+                grads.add(conv.weight, grad_weight_rows(dlo_r, _Rows(lo), mlo))
+                grads.add(conv.bias, dlo_r.colsum())
                 drows = torch.empty(mlo, lo.shape[1], device=dev, dtype=torch.float32)
                 ops.gemm(dlo, mlo, lo.shape[1], cn, [WT.get(_w2d(conv.weight), conv.weight)], drows)
             elif kind == "down":
                 conv, pooled, (bb, lh, lw) = sv["conv"], sv["pooled"], sv["shape"]
                 mlo = bb * lh * lw
-                dr_t, dbd = _T_colsum(drows)
-                grads.add(conv.weight, grad_weight(dr_t, _T(pooled), mlo))
-                grads.add(conv.bias, dbd)
+                dr_r = _Rows(drows)
+                grads.add(conv.weight, grad_weight_rows(dr_r, _Rows(pooled), mlo))
+                grads.add(conv.bias, dr_r.colsum())
                 dpool = torch.empty(mlo, pooled.shape[1], device=dev, dtype=torch.float32)
                 ops.gemm(drows, mlo, pooled.shape[1], conv.weight.shape[0], [WT.get(_w2d(conv.weight), conv.weight)], dpool)
                 hi = dskip.pop(sv["level"]).clone()                         # start from the skip gradient, add the pooled path

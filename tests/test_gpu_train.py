@@ -21,6 +21,31 @@ def formula(module, gain=1.0):
     return module.cuda()
 
 
+@pytest.mark.parametrize("M,N,K,S", [(64, 128, 128, 1), (4096, 256, 128, 4), (2048, 128, 384, 2), (96, 384, 256, 3)])
+def test_gemm_tn_weight_gradient_kernel(gpu_device, M, N, K, S):
+    """dW = dY^T X straight from the row-major operands (no transposed copies): every split plane and their sum."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).cuda()
+    x = torch.randn(M, K, generator=g).cuda()
+    parts = torch.empty(S, N, K, device=gpu_device)
+    cs = torch.empty(S, N, device=gpu_device)
+    ops.gemm_tn(dy, x, parts, M, N, K, S, colsum=cs)
+    assert rel_l2(cs.sum(0).double().cpu(), dy.double().sum(0).cpu()) < 1e-5
+    ms = M // S
+    for s_ in range(S):
+        ref = dy[s_ * ms:(s_ + 1) * ms].double().t() @ x[s_ * ms:(s_ + 1) * ms].double()
+        assert rel_l2(parts[s_].double().cpu(), ref.cpu()) < 1e-5, s_
+    out = torch.empty(N, K, device=gpu_device)
+    ops.reduce_partials(parts, S, N * K, out)
+    assert rel_l2(out.double().cpu(), (dy.double().t() @ x.double()).cpu()) < 1e-5
+    # leading dimension wider than N (the first N columns of a wider matrix)
+    wide = torch.randn(M, N + 128, generator=g).cuda()
+    ops.gemm_tn(wide, x, parts, M, N, K, S, lda=N + 128)
+    ops.reduce_partials(parts, S, N * K, out)
+    assert rel_l2(out.double().cpu(), (wide[:, :N].double().t() @ x.double()).cpu()) < 1e-5
+
+
 def test_backward_kernels_against_autograd(gpu_device):
     from ldm_image_generator_amd import ops
     g = torch.Generator().manual_seed(0)
