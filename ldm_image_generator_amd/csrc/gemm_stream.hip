@@ -427,6 +427,9 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
         if (gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, true, LDM_A_ROWS, true>(p, groups, st);
         if (!gate && amode == LDM_A_CONV3X3 && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3, true>(p, groups, st);
         if (!gate && amode == LDM_A_ROWS && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS, true>(p, groups, st);
+        // N = 64 (VAE stage 3): 64x32 per wave, three splits feed two tiles -- still ahead of the exact instruction
+        if (!gate && amode == LDM_A_CONV3X3 && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_CONV3X3, true>(p, groups, st);
+        if (!gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_ROWS, true>(p, groups, st);
     }
     if (gate) {
         if (amode != LDM_A_ROWS) return 0;

@@ -345,7 +345,7 @@ def test_gemm_split_schedule_fp32_level_error(gpu_device):
         assert e2 < KTOL and e2 < 4 * e1 + 1e-7, (what, e1, e2)
         assert not torch.equal(outs[0], outs[1]), what + ": schedule 2 did not run"
 
-    for (M, N, K) in [(70000, 128, 128), (4100, 1024, 64), (257, 256, 96), (33000, 384, 32)]:
+    for (M, N, K) in [(70000, 128, 128), (4100, 1024, 64), (257, 256, 96), (33000, 384, 32), (9000, 64, 160)]:
         a, w, b = rnd(M, K).cuda(), rnd(N, K, seed=1, scale=K ** -0.5).cuda(), rnd(N, seed=2).cuda()
         add = rnd(M, N, seed=3).cuda()
 
@@ -394,6 +394,18 @@ def test_gemm_split_schedule_fp32_level_error(gpu_device):
     cref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xn, w4.double(), bc.cpu().double(), padding=1), 0.01)
     cref = cref.permute(0, 2, 3, 1).reshape(M, C) + xc.cpu().double()
     check(both(conv), cref, "conv3x3")
+    # N = 64 dense conv (VAE stage-3 shape class)
+    C2 = 64
+    xc2 = rnd(M, C2).cuda()
+    w42 = rnd(C2, C2, 3, 3, seed=7, scale=(9 * C2) ** -0.5)
+    wk2 = w42.permute(0, 2, 3, 1).reshape(C2, 9 * C2).contiguous().cuda()
+
+    def conv64():
+        y = torch.empty(M, C2, device=gpu_device)
+        o.gemm(xc2, M, C2, 9 * C2, [wk2], y, lda=C2, ldw=9 * C2, a_mode=o.A_CONV3X3, conv_hw=(R, R), cin=C2)
+        return y
+    xn2 = xc2.cpu().double().reshape(B, R, R, C2).permute(0, 3, 1, 2)
+    check(both(conv64), torch.nn.functional.conv2d(xn2, w42.double(), padding=1).permute(0, 2, 3, 1).reshape(M, C2), "conv3x3 N=64")
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(16, 1024, 3072, "kseg"), (64, 512, 1536, "kseg"), (64, 1536, 512, "gate"), (16, 3072, 1024, "gate"),
