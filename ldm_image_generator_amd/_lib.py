@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libldm_hip.so")
+LIB_PATH = os.environ.get("LDM_HIP_LIB") or os.path.join(HERE, "libldm_hip.so")     # LDM_HIP_LIB: A/B another build
 
 LDM_MAX_SEG = 4
 ACT_NONE, ACT_RELU, ACT_GATE, ACT_LRELU = 0, 1, 2, 3

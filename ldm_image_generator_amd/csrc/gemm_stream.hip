@@ -16,6 +16,7 @@
 // are never stored); zero padding of the implicit 3x3 im2col reads a 64-B block of zeros.
 #include "gemm_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 using namespace ldmgemm;
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ void mfma6(const Split3 &a, const Split3 &b, f32x16 &
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false, bool WIDE = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     float pre[TM][TN][16];
     const WideLane<TN> wl = wide_lane<TN>(lane);
     f32x4 fa0[TM], fb0[NACC][TN], fa1[TM], fb1[NACC][TN];        // two fragment sets (ping-pong over j); SPLIT: the two chunks of a half
-    Split3 sa[SPLIT ? TM : 1], sb[SPLIT ? NACC : 1][SPLIT ? TN : 1];
+    Split3 sa[SPLIT ? TM : 1], sb[SPLIT ? NACC : 1][SPLIT ? TN : 1];   // SPLIT: 0 exact fp32, 1 split, 2 split with paced interleave
     if (my_tiles == 0) return;
     // accumulators are cleared here and again right after each tile's epilogue -- NOT by a per-step
     // "c_kt == 0 ? 0 : acc" select, which would put 16 VALU selects per accumulator tile (each waiting
@@ -277,39 +278,54 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
                 fb1[q][i] = *(const f32x4 *)(Bs + swz(q * BN + (wn * TN + i) * 32 + r, c1));
             }
     };
-    auto split_all = [&]() {
-        if constexpr (SPLIT) {
+    // One half (16 k) of a K-step of the split consumer.  A split is 44 VALU instructions, a tile 6 MFMAs (192 matrix
+    // cycles, of which the issuing wave is held for 48): each tile's MFMAs are interleaved with the split of the NEXT
+    // operand some later tile needs (sched_group_barrier: 1 MFMA, 8 VALU, ...), so only the first two splits of a half
+    // are exposed.  `mid` runs at the point where all raw fragment registers have been consumed (the next half's reads,
+    // or the step's sync point, go there).
+    auto split_b = [&](int bi) { split3(fb0[bi / TN][bi % TN], fb1[bi / TN][bi % TN], sb[bi / TN][bi % TN]); };
+    auto tile_mma = [&](int a, int bi) { mfma6(sa[a], sb[bi / TN][bi % TN], acc[bi / TN][a][bi % TN]); };
+    auto interleave = [&]() {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) split3(fa0[i], fa1[i], sa[i]);
-#pragma unroll
-            for (int q = 0; q < NACC; ++q)
-#pragma unroll
-                for (int i = 0; i < TN; ++i) split3(fb0[q][i], fb1[q][i], sb[q][i]);
+        for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
         }
     };
-    // part 0 / 1: first / second half of the wave's accumulator tiles (part < 0: all of them)
-    auto mma_split = [&](int part) {
+    auto split_half = [&](auto mid, auto paced, auto mid_early) {
         if constexpr (SPLIT) {
-            constexpr int NT = NACC * TM * TN;
+            constexpr int NB = NACC * TN;
+            static_assert(TM == 2 && (NB == 1 || NB == 2), "split consumer: 2 x {1, 2} tiles per wave");
+            if constexpr (!decltype(paced)::value || SPLIT != 2) {   // unpaced: all splits, then all MFMAs; the scheduler is free
+                split3(fa0[0], fa1[0], sa[0]);
+                split3(fa0[1], fa1[1], sa[1]);
 #pragma unroll
-            for (int q = 0; q < NACC; ++q)
+                for (int bi = 0; bi < NB; ++bi) split_b(bi);
+                if constexpr (decltype(mid_early)::value) mid();      // first half: the second half's reads fly under all MFMAs
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int bi = 0; bi < NB; ++bi) tile_mma(0, bi);
+                if constexpr (!decltype(mid_early)::value) mid();     // second half: the sync point sits before the last MFMAs
 #pragma unroll
-                    for (int jj = 0; jj < TN; ++jj) {
-                        const int idx = (q * TM + i) * TN + jj;
-                        const bool first = idx < (NT + 1) / 2;
-                        if (part < 0 || (part == 0) == first) mfma6(sa[i], sb[q][jj], acc[q][i][jj]);
-                    }
+                for (int bi = 0; bi < NB; ++bi) tile_mma(1, bi);
+                return;
+            }
+            split3(fa0[0], fa1[0], sa[0]);
+            split_b(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NB == 2) {
+                split_b(1);
+                tile_mma(0, 0);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            split3(fa0[1], fa1[1], sa[1]);
+            tile_mma(0, NB - 1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            tile_mma(1, 0);
+            if constexpr (NB == 2) tile_mma(1, 1);
         }
-    };
-    // one K-step of the split consumer up to (not including) the next stage's first fragment read
-    auto split_step_head = [&](int s_) {
-        split_all();                                      // half 0 (read during the previous step)
-        read_half(s_, 1);                                 // in flight under the MFMAs below
-        mma_split(-1);
-        split_all();                                      // half 1
-        mma_split(0);
     };
 
     // ---- prologue: stage 0 <- step 0 -------------------------------------------
@@ -331,10 +347,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         for (int kt = 0; kt < nk - 1; ++kt, ++s) {
             loader_issue();                               // step s+1 (exists: this is not the tile's last step)
             if constexpr (SPLIT) {
-                split_step_head(s);
-                sync_point();
-                read_half(s + 1, 0);
-                mma_split(1);
+                split_half([&]() { read_half(s, 1); }, std::true_type{}, std::true_type{});
+                split_half([&]() {
+                    sync_point();
+                    read_half(s + 1, 0);
+                }, std::true_type{}, std::false_type{});
             } else {
                 quarters_0_to_2(s);
                 sync_point();
@@ -356,10 +373,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
             if (use_pre) gemm_prefetch_addend<WM, WN, TM, TN>(p, pre, c_m0, c_n0, c_g, wm, wn, r, h);
         }
         if constexpr (SPLIT) {
-            split_step_head(s);
-            sync_point();
-            if (more) read_half(s + 1, 0);
-            mma_split(1);
+            split_half([&]() { read_half(s, 1); }, std::false_type{}, std::true_type{});
+            split_half([&]() {
+                sync_point();
+                if (more) read_half(s + 1, 0);
+            }, std::false_type{}, std::false_type{});
         } else {
             quarters_0_to_2(s);
             sync_point();
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false, bool WIDE = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false>
 int launch_stream(const GemmP &p, int groups, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -400,7 +418,7 @@ int launch_stream(const GemmP &p, int groups, hipStream_t st)
     return 1;
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, bool SPLIT = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0>
 int launch_stream_w(const GemmP &p, int groups, hipStream_t st)
 {
     if (p.wide_ok && g_wide) return launch_stream<WM, WN, TM, TN, GATE, AMODE, SPLIT, true>(p, groups, st);
@@ -423,13 +441,19 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
     const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
     if (split && p.M > 128) {
         // split schedule: wave tiles of 64x64 (or 64x32 x two gate matrices) so that each split fragment feeds two
-        // tiles; shapes it does not cover (grouped conv N = 32, tiny M) fall through to the exact-fp32 instances
-        if (gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, true, LDM_A_ROWS, true>(p, groups, st);
-        if (!gate && amode == LDM_A_CONV3X3 && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3, true>(p, groups, st);
-        if (!gate && amode == LDM_A_ROWS && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS, true>(p, groups, st);
+        // tiles; shapes it does not cover (grouped conv N = 32, tiny M) fall through to the exact-fp32 instances.
+        // "paced" (SPLIT = 2) pins each tile's MFMAs over the next operand's split with sched_group_barrier: +3-8 %
+        // when the A operand is cache-resident (deep stages, conv taps), -10 % when it streams from HBM (the fences
+        // take away the scheduler's freedom around the DMA wait), hence the size test
+        const bool paced = amode == LDM_A_CONV3X3 || (long long)p.M * p.K * 4 <= (48ll << 20);
+        if (gate && amode == LDM_A_ROWS && unit % 64 == 0)
+            return paced ? launch_stream_w<2, 2, 2, 1, true, LDM_A_ROWS, 2>(p, groups, st) : launch_stream_w<2, 2, 2, 1, true, LDM_A_ROWS, 1>(p, groups, st);
+        if (!gate && amode == LDM_A_CONV3X3 && unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3, 2>(p, groups, st);
+        if (!gate && amode == LDM_A_ROWS && unit % 128 == 0)
+            return paced ? launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS, 2>(p, groups, st) : launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS, 1>(p, groups, st);
         // N = 64 (VAE stage 3): 64x32 per wave, three splits feed two tiles -- still ahead of the exact instruction
-        if (!gate && amode == LDM_A_CONV3X3 && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_CONV3X3, true>(p, groups, st);
-        if (!gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_ROWS, true>(p, groups, st);
+        if (!gate && amode == LDM_A_CONV3X3 && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_CONV3X3, 2>(p, groups, st);
+        if (!gate && amode == LDM_A_ROWS && unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_ROWS, 1>(p, groups, st);
     }
     if (gate) {
         if (amode != LDM_A_ROWS) return 0;
