@@ -76,6 +76,8 @@ def main():
 
     rank, world, local = ldist.init_from_env()
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if os.environ.get("LDM_BENCH_ONE_DEVICE"):      # rehearsal of the multi-rank path on a one-GPU box (with LDM_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
