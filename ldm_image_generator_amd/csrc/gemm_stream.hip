@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     int a_y[A_F4], a_x[A_F4];
     const int seg_steps = p.seg_mode == LDM_SEG_K ? p.seg_len >> 5 : 0x7fffffff;   // K-steps per weight segment
     int l_nloc0 = 0;
+    int l_m0 = 0, l_n0 = 0, l_seg_n = 0;         // coordinates of the loader's current tile
+    int i_g = 0, i_m0 = 0, i_n0 = 0, i_seg_n = 0;  // ... of the tile whose FIRST K-step was issued last (the consumer takes them over)
 
     auto weight_rows = [&]() {
         const long long off = (long long)l_nloc0 * p.ldw;
@@ -136,7 +138,10 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     auto loader_setup = [&]() {
         int m0, n0;
         tile_coords(l_tile, l_g, m0, n0);
+        l_m0 = m0;
+        l_n0 = n0;
         l_seg = (p.seg_mode == LDM_SEG_N) ? n0 / p.seg_len : 0;
+        l_seg_n = l_seg;
         l_nloc0 = (p.seg_mode == LDM_SEG_N) ? n0 - l_seg * p.seg_len : n0;
         l_kin = 0;
         l_tap = 0;
@@ -164,6 +169,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
 
     auto loader_issue = [&]() {
         float *As = lds + (l_step & 1) * STAGE, *Bs = As + BM * 32;
+        const bool first = l_kt == 0;                 // branch-free hand-over of the tile coordinates
+        i_g = first ? l_g : i_g;
+        i_m0 = first ? l_m0 : i_m0;
+        i_n0 = first ? l_n0 : i_n0;
+        i_seg_n = first ? l_seg_n : i_seg_n;
         if (AMODE == LDM_A_CONV3X3) {
             const int dy = l_tap / 3 - 1, dx = l_tap - (l_tap / 3) * 3 - 1;
             const float *a_tap = a_cur + ((long long)(dy * p.W + dx) * p.lda + (l_cin << 5));
@@ -340,8 +350,9 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
     int s = 0;                                            // position in this workgroup's K-step stream
 #pragma unroll 1
     for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
-        int c_g, c_m0, c_n0;
-        tile_coords(c_tile, c_g, c_m0, c_n0);
+        // the loader runs exactly one K-step ahead: the last FIRST-step it issued belongs to this tile.  Take its
+        // coordinates over instead of recomputing them (tile order = an xcd remap and three integer divisions)
+        const int c_g = i_g, c_m0 = i_m0, c_n0 = i_n0, c_seg_n = i_seg_n;
         clear_acc();
 #pragma unroll 1
         for (int kt = 0; kt < nk - 1; ++kt, ++s) {
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
         const bool more = s + 1 < total_steps;
         if (more) loader_issue();
         const bool use_pre = p.addend != nullptr && p.o_mode == LDM_O_ROWS;
-        const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
+        const int seg_n = c_seg_n;
         EpiCols<TN> cols;
         gemm_epilogue_cols<WN, TN, GATE>(p, cols, c_n0, c_g, seg_n, wn, r);
         if constexpr (WIDE) {
