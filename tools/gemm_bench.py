@@ -65,7 +65,7 @@ if __name__ == "__main__":
     variants = [int(v) for v in sys.argv[1:]] or [0, 1]
     if os.environ.get("GEMM_WIDE") is not None:
         ops.gemm_wide_epilogue(int(os.environ["GEMM_WIDE"]))
-    cs = cases()
+    cs = cases(int(os.environ.get('GEMM_BATCH', '256')))
     flt = os.environ.get('GEMM_CASES')
     if flt:
         cs = [c for c in cs if any(f in c[0] for f in flt.split(','))]
