@@ -182,26 +182,41 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
     }
 }
 
-// head: NHWC -> NCHW, ConvTranspose 1x1 (w [C0, Cin]); 64 pixels per block, C0 walked in chunks of 128
+// head: NHWC -> NCHW, ConvTranspose 1x1 (w [C0, Cin]); 64 pixels per block, C0 walked in chunks of 128.
+// The chunk's weights are staged in LDS once per block and read as wave-wide broadcasts (wave cg owns outputs
+// cg, cg + 4, cg + 8, cg + 12); the pixel tile is read conflict-free (row stride 129).
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                    const float *__restrict__ bias, float *__restrict__ out, long long M,
                                                    int C0, int HW, int Cin)
 {
     __shared__ float tile[64 * 129];
+    __shared__ float wl[128 * 16];
     const int t = threadIdx.x, p = t & 63, cg = t >> 6;
     const long long m0 = (long long)blockIdx.x * 64;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};          // outputs cg, cg+4, cg+8, cg+12  (Cin <= 16)
     for (int c0 = 0; c0 < C0; c0 += 128) {
         const int cw = min(128, C0 - c0);
-        for (int i = t; i < 64 * cw; i += 256) {
-            const int rr = i / cw, cc = i - rr * cw;
-            const long long m = m0 + rr;
-            tile[rr * 129 + cc] = m < M ? x[m * C0 + c0 + cc] : 0.f;
+        if (cw == 128) {                          // 32 float4 per pixel row: coalesced 16-byte loads, no division
+            for (int i = t; i < 64 * 32; i += 256) {
+                const int rr = i >> 5, c4 = (i & 31) * 4;
+                const long long m = m0 + rr;
+                f32x4 v{0.f, 0.f, 0.f, 0.f};
+                if (m < M) v = *(const f32x4 *)(x + m * C0 + c0 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[rr * 129 + c4 + e] = v[e];
+            }
+        } else {
+            for (int i = t; i < 64 * cw; i += 256) {
+                const int rr = i / cw, cc = i - rr * cw;
+                const long long m = m0 + rr;
+                tile[rr * 129 + cc] = m < M ? x[m * C0 + c0 + cc] : 0.f;
+            }
         }
+        for (int i = t; i < cw * Cin; i += 256) wl[i] = w[(long long)c0 * Cin + i];
         __syncthreads();
         for (int c = 0; c < cw; ++c) {
             const float xv = tile[p * 129 + c];
-            const float *wr = w + (long long)(c0 + c) * Cin;
+            const float *wr = wl + c * Cin;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int co = cg + 4 * k;
@@ -411,6 +426,7 @@ extern "C" int ldm_head_nchw_f32(const float *x, const float *w, const float *bi
 {
     LDM_REQUIRE(x && w && out, "ldm_head_nchw_f32: null pointer");
     LDM_REQUIRE(B > 0 && C0 > 0 && HW > 0 && Cin > 0 && Cin <= 16, "ldm_head_nchw_f32: bad shape (Cin=%d must be <= 16)", Cin);
+    LDM_REQUIRE(C0 % 4 != 0 || ldm_aligned16(x), "ldm_head_nchw_f32: unaligned input");
     const long long M = (long long)B * HW;
     hipLaunchKernelGGL(head_kernel, dim3(blocks_for(M, 64)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, M, C0, HW, Cin);
     LDM_CHECK_LAUNCH("ldm_head_nchw_f32");
