@@ -2,15 +2,15 @@
 //
 // Through the generic stream GEMM this op is an implicit-im2col problem with N = 32: every K-step (one tap) re-fetches
 // a 128-pixel x 32-channel A tile for only 16 MFMAs per wave, i.e. 5 LDS-DMA instructions per 1024 MFMA cycles -- the
-// kernel sits at MFMA-busy 0.50, paced by DMA issue.  Here a workgroup loads, ONCE, the flattened pixel range
-// [m0 - W - 1, m0 + 128 + W + 1) of its group's 32 channels (every 3x3 neighbour of pixel m is pixel m + dy*W + dx of
-// that range) plus the group's 9 x 32 x 32 weights, then runs all nine taps out of LDS: 15 DMA instructions per
-// 9216 MFMA cycles.  Image borders are handled at fragment-read time: an invalid neighbour reads a zero row.
+// kernel sits at MFMA-busy 0.50, paced by DMA issue.  Here a workgroup loads, ONCE per tile, the flattened pixel range
+// [m0 - W - 1, m0 + 256 + W + 1) of its group's 32 channels (every 3x3 neighbour of pixel m is pixel m + dy*W + dx of
+// that range) and, once per group, the 9 x 32 x 32 weights, then runs all nine taps out of LDS: about 5 DMA
+// instructions per wave per 9216 MFMA cycles.  Image borders are handled at fragment-read time: an invalid neighbour
+// reads a zero row.
 //
 // Same k-order as the stream / tile GEMM kernels (tap-major, then the (quarter, e, half-wave) map of their K-steps),
 // so results are bit-identical to the generic path.
 #include "gemm_common.h"
-#include <cstdlib>
 
 using namespace ldmgemm;
 
