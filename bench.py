@@ -63,6 +63,8 @@ def main():
                     help="what the single all-gather moves: the fp32 images SURVEY 8(d) defines the metric on (default), or the "
                          "device-side uint8 HWC post-process of sample_ldm.py:75-77 (a quarter of the bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-mode-leg", action="store_true",
+                    help="skip the secondary measurement in the reference-faithful mode (no .eval(): stochastic depth live)")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the secondary measurement under GEMM schedule 2 (bf16x3 split consumer)")
     args = ap.parse_args()
@@ -133,6 +135,19 @@ def main():
     # secondary leg, never the headline: the same passes under GEMM schedule 2 (fp32 operands cut exactly into three
     # bf16 pieces, six bf16 MFMAs per product, fp32 accumulate -- DESIGN.md 3.1), with its deviation from the
     # exact-fp32 images of the same seed
+    # secondary leg: what the reference's scripts actually do -- they never call .eval(), so SwinBlocks are skipped with
+    # p = 0.25 during sampling too (unet.py:39); fewer FLOPs per image, hence reported beside, not as, the headline
+    train_leg = None
+    if not args.no_train_mode_leg and args.mode == "eval":
+        net.train(True)
+        dt3, (l3, ms3, fl3), out3 = measure(1, args.steps)
+        net.train(False)
+        train_leg = {"value": gb * args.steps / dt3, "unit": "images/s", "ms_per_step": dt3 / args.steps * 1e3,
+                     "gemm_tflops": fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else None,
+                     "executed_gflop_per_sample_step": fl3 / 1e9 / (B * args.steps) / T if rank == 0 else None,
+                     "outputs_finite": bool(torch.isfinite(out3.float()).all().item()),
+                     "note": "reference-faithful train mode (stochastic depth live while sampling), same seeds"}
+        del out3
     split = None
     if not args.no_split_leg:
         keep = out[: min(16, out.shape[0])].clone()
@@ -175,6 +190,8 @@ def main():
             line["roofline"]["traffic"] = tj["gemm_hbm_bytes_per_launch"]
             line["roofline"]["traffic_unit"] = "bytes per GEMM launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.md)"
             line["roofline"]["algorithmic_bytes_per_launch"] = None
+        if train_leg is not None:
+            line["train_mode"] = train_leg
         if split is not None:
             line["split_schedule"] = split
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N = 1 only

@@ -12,13 +12,13 @@ cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-split-leg > $OUT/${TAG}_stats.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-split-leg --no-train-mode-leg > $OUT/${TAG}_stats.log 2>&1
 echo "stats done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline --no-split-leg > $OUT/${TAG}_pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline --no-split-leg --no-train-mode-leg > $OUT/${TAG}_pmc_fetch.log 2>&1
 echo "fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline --no-split-leg > $OUT/${TAG}_pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline --no-split-leg --no-train-mode-leg > $OUT/${TAG}_pmc_write.log 2>&1
 echo "write done"
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline --no-split-leg > $OUT/${TAG}_pmc_mfma.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -o ${TAG} -- python3 $ROOT/bench.py --steps 1 --warmup 0 --num-steps 2 --no-cpu-baseline --no-split-leg --no-train-mode-leg > $OUT/${TAG}_pmc_mfma.log 2>&1
 echo "mfma done"
 # the raw kernel-trace CSVs are large; keep only what the summaries need
 find $OUT/${TAG}_stats -name "*kernel_trace.csv" -delete
