@@ -221,6 +221,198 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_kernel(const GemmP p, int nt
     }
 }
 
+// ---- software-pipelined variant (M a multiple of 256: every tile is full) ---------------------------------------------
+// With one dependent MFMA chain per wave, a wave can only do other work in the gaps between its MFMAs, and the per-tile
+// workgroup barrier keeps all waves of a workgroup in phase -- so the ~2000 instructions of per-tile set-up and epilogue
+// of the kernel above are exposed.  Here they are cut into chunks of about a dozen instructions and placed behind each
+// 4-MFMA group of the K loop (where the matrix pipe is busy for another 64 cycles anyway):
+//   * quarter 0 .. 11  : the NEXT tile's pixel coordinates (reciprocal-multiply division) and its nine neighbour slots,
+//   * quarter 12 .. 27 : the NEXT tile's addend loads,
+//   * quarter 20 .. 35 : the PREVIOUS tile's 16 output stores (its values were finalised right after its MFMAs).
+struct GcTile {
+    int aoff[9], asw[9];
+    float pre[16];
+    float bias;
+    float *obase;
+};
+
+__global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, int ntm, int total, int chunk, float inv_w, float inv_h)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int W = p.W, H = p.H;
+    const int NP = BM + 2 * W + 2;
+    const int NPp = (NP + 7) & ~7;
+    const int npieces = NPp / 8;
+    float *Zs = lds, *Ab = lds + 32, *Ws = Ab + 2 * NPp * 32;
+    const int first = (int)blockIdx.x * chunk;
+    const int last = first + chunk < total ? first + chunk : total;
+    if (first >= last) return;
+
+    auto a_piece = [&](int id, int k, float *dst) {
+        const int g = id / ntm, m0 = (id - g * ntm) * BM;
+        const int slot = 8 * k + (lane >> 3), cpos = lane & 7;
+        int m = m0 - W - 1 + slot;
+        m = m < 0 ? 0 : (m < p.M ? m : p.M - 1);
+        glds16(p.a + g * p.a_gstride + (long long)m * p.lda + ((cpos ^ ((slot >> 1) & 7)) << 2), dst + k * 256);
+    };
+    auto w_load = [&](int g) {
+        const float *wbase = p.w[0] + g * p.w_gstride;
+        for (int q0 = wave * 64; q0 < 9 * 32 * 8; q0 += NW * 64) {
+            const int q = q0 + lane;
+            const int row = q >> 3, cpos = q & 7;
+            const int tap = row >> 5, n = row & 31;
+            glds16(wbase + (long long)n * p.ldw + tap * 32 + ((cpos ^ ((row >> 1) & 7)) << 2), Ws + q0 * 4);
+        }
+    };
+    // exact x / d for 0 <= x < 2^24 via a float reciprocal and one correction step each way
+    auto divmod = [](int x, int d, float inv, int &q, int &rem) {
+        q = (int)((float)x * inv);
+        rem = x - q * d;
+        const bool hi = rem >= d, lo = rem < 0;
+        q += hi ? 1 : (lo ? -1 : 0);
+        rem += hi ? -d : (lo ? d : 0);
+    };
+    // per-tile pieces -------------------------------------------------------------------------------------------------
+    int nx = 0, ny = 0, nrow = 0, nslot0 = 0, nbuf = 0;      // next tile's pixel of this lane
+    const float *n_abase = nullptr;
+    int n_lda = 0, n_g = 0, n_m0 = 0;
+    // three chunks, one per MFMA group: tile -> (group, first pixel) and x; y; output / addend pointers
+    auto next_coords0 = [&](int id) {
+        n_g = id / ntm;
+        n_m0 = (id - n_g * ntm) * BM;
+        divmod(n_m0 + wave * 32 + r, W, inv_w, nrow, nx);
+    };
+    auto next_coords1 = [&](int bufsel) {
+        int tmp;
+        divmod(nrow, H, inv_h, tmp, ny);
+        nslot0 = wave * 32 + r + W + 1;
+        nbuf = 32 + bufsel * NPp * 32;                        // float offset of the pixel block inside lds
+    };
+    auto next_coords2 = [&](GcTile &T) {
+        const int col = n_g * (int)p.o_gstride + r;
+        const long long row_first = n_m0 + wave * 32 + 4 * h;
+        T.bias = *(p.bias[0] ? p.bias[0] + n_g * p.b_gstride + r : ldm_zero_block);
+        T.obase = p.out + row_first * p.ldo + col;
+        n_abase = p.addend ? p.addend + row_first * p.ldadd + col : ldm_zero_block;
+        n_lda = p.addend ? (int)p.ldadd : 0;
+    };
+    auto next_tap = [&](int tap, GcTile &T) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const bool ok = (unsigned)(ny + dy) < (unsigned)H && (unsigned)(nx + dx) < (unsigned)W;
+        const int slot = nslot0 + dy * W + dx;
+        T.aoff[tap] = ok ? nbuf + slot * 32 : 0;              // outside the image: the zero row at lds[0]
+        T.asw[tap] = ok ? (slot >> 1) & 7 : 0;
+    };
+    auto next_pre = [&](int e, GcTile &T) { T.pre[e] = n_abase[((e & 3) + 8 * (e >> 2)) * n_lda]; };
+
+    if (t < 8) *(f32x4 *)(Zs + t * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur_g = first / ntm;
+    w_load(cur_g);
+    for (int k = wave; k < npieces; k += NW) a_piece(first, k, Ab);
+    GcTile C, N;
+    next_coords0(first);
+    next_coords1(0);
+    next_coords2(C);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) next_tap(tap, C);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) next_pre(e, C);
+    N = C;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int wsw = (r >> 1) & 7;
+    int woff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = r * 32 + (((2 * j + h) ^ wsw) << 2);
+    const unsigned ws_addr = (unsigned)(size_t)(lptr_t)Ws, lds_addr = (unsigned)(size_t)(lptr_t)lds;
+    const float slope = p.act == LDM_ACT_LRELU ? p.slope : 1.f;
+    const bool relu = p.act == LDM_ACT_RELU, has_add = p.addend != nullptr;
+    const int ldo_e = (int)p.ldo;
+
+    float outv[16];                                           // previous tile's finished values, stored under this tile's MFMAs
+    float *obase_prev = nullptr;
+    bool pending = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) outv[e] = 0.f;
+
+#pragma unroll 1
+    for (int id = first; id < last; ++id) {
+        const int g = id / ntm;
+        float *An = Ab + ((id - first + 1) & 1) * NPp * 32;
+        if (g != cur_g) {
+            cur_g = g;
+            w_load(g);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const int idn = id + 1 < last ? id + 1 : id;           // clamped: the last tile "prepares" itself again (unused)
+        if (id + 1 < last)
+            for (int k = wave; k < npieces; k += NW) a_piece(id + 1, k, An);
+
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        auto frag = [&](int idx, f32x4 &af, f32x4 &bf) {
+            const int tap = idx >> 2, j = idx & 3;
+            af = lds_read16(lds_addr + 4u * (unsigned)(C.aoff[tap] + (((2 * j + h) ^ C.asw[tap]) << 2)));
+            bf = lds_read16(ws_addr + 4u * (unsigned)(tap * 1024 + woff[j]));
+        };
+        auto mma = [&](const f32x4 &af, const f32x4 &bf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+        };
+        // the chunk of side work that rides behind MFMA group q
+        auto extra = [&](int q) {
+            if (q == 0) next_coords0(idn);
+            if (q == 1) next_coords1((id - first + 1) & 1);
+            if (q == 2) next_coords2(N);
+            if (q >= 3 && q <= 11) next_tap(q - 3, N);
+            if (q >= 12 && q <= 27) next_pre(q - 12, N);
+            if (q >= 20 && pending) obase_prev[(((q - 20) & 3) + 8 * ((q - 20) >> 2)) * ldo_e] = outv[q - 20];
+        };
+        f32x4 a0, a1, b0, b1;
+        frag(0, a0, b0);
+#pragma unroll
+        for (int idx = 0; idx < 36; idx += 2) {
+            lds_wait(a0, b0);
+            frag(idx + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            extra(idx);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait(a1, b1);
+            if (idx + 2 < 36) frag(idx + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            extra(idx + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // finalise this tile's values (stored under the next tile's MFMAs, or by the flush below)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = acc[e] + C.bias;
+            const float vr = fmaxf(v, 0.f), vl = v > 0.f ? v : v * slope;
+            v = relu ? vr : vl;
+            if (has_add) v += C.pre[e];
+            outv[e] = v;
+        }
+        obase_prev = C.obase;
+        pending = true;
+        C = N;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) obase_prev[((e & 3) + 8 * (e >> 2)) * ldo_e] = outv[e];
+}
+
 }  // namespace
 
 // Returns 1 if the problem is a 32-in / 32-out-per-group 3x3 convolution this kernel covers (and launches it), else 0.
@@ -237,6 +429,7 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
     static int cus = 0;
     if (cus == 0) {
         (void)hipFuncSetAttribute((const void *)gconv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)gconv3x3_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         int dev = 0;
         cus = 256;
         (void)hipGetDevice(&dev);
@@ -244,6 +437,11 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
     }
     const int wgs = (int)(total < cus ? total : cus);
     const int chunk = (int)((total + wgs - 1) / wgs);
-    hipLaunchKernelGGL(gconv3x3_kernel, dim3((unsigned)((total + chunk - 1) / chunk)), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
+    const unsigned grid = (unsigned)((total + chunk - 1) / chunk);
+    if (p.M % BM == 0 && p.M < (1 << 24) && p.ldo * 64ll < 0x7fffffffLL)          // every tile full: the software-pipelined variant
+        hipLaunchKernelGGL(gconv3x3_pipe_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
+                           1.0f / (float)p.H);
+    else
+        hipLaunchKernelGGL(gconv3x3_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
     return 1;
 }

@@ -113,6 +113,7 @@ def test_grouped_conv3x3_dedicated_kernel_bit_identical(gpu_device):
     from ldm_image_generator_amd import ops as o
     for (B, H, W, C, act, with_add) in [(3, 32, 32, 128, o.ACT_NONE, True), (5, 7, 5, 64, o.ACT_RELU, True),
                                         (70, 4, 4, 256, o.ACT_NONE, False), (2, 12, 64, 64, o.ACT_LRELU, True),
+                                        (64, 4, 4, 1024, o.ACT_NONE, True), (16, 16, 16, 512, o.ACT_RELU, False),
                                         (1, 40, 96, 64, o.ACT_NONE, True)]:
         M = B * H * W
         rows = rnd(M, C).cuda()
