@@ -307,6 +307,49 @@ def test_sharded_sampling_uint8_postprocess_before_gather(gpu_device):
     assert torch.equal(u8, to_uint8_images(f32))
 
 
+def test_decoder_and_unet_replay_from_a_hip_graph(gpu_device, tiny_unet):
+    """include/ldm_hip.h promises that every entry point only enqueues on the given stream and is capturable: record
+    one Decoder forward and one UNet forward (fixed expert / depth decisions; the shared timestep lives in a 1-element
+    device tensor, as in DDPM.sample) into a HIP graph, replay on new inputs and a new timestep, compare with eager."""
+    from ldm_image_generator_amd.vae import Decoder
+    dec = formula(Decoder(channels=[64, 32, 32], stages=[1, 2, 1]))
+    tiny_unet.eval()
+    z = torch.randn(2, 8, 6, 5, device=gpu_device)
+    x = torch.randn(2, 8, 32, 32, device=gpu_device)
+    t1 = torch.tensor([500], dtype=torch.int64, device=gpu_device)
+    tt = torch.full((2,), 500, device=gpu_device)
+
+    def forward():
+        random.seed(3)                                   # the decisions are baked into the recorded launches
+        tiny_unet._uniform_time = (500, t1)
+        try:
+            return dec(z), tiny_unet(x, tt)
+        finally:
+            tiny_unet._uniform_time = None
+
+    with torch.no_grad():
+        forward()                                        # warm-up outside capture (lazy caches, function attributes)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            forward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            img, eps = forward()
+        z.copy_(torch.randn(2, 8, 6, 5, device=gpu_device))
+        x.copy_(torch.randn(2, 8, 32, 32, device=gpu_device))
+        t1.fill_(37)
+        graph.replay()
+        torch.cuda.synchronize()
+        got_img, got_eps = img.clone(), eps.clone()
+        ref_img, ref_eps = forward()
+        random.seed(3)
+        ref_eps2 = tiny_unet(x, torch.full((2,), 37, device=gpu_device))
+    assert torch.equal(got_img, ref_img) and torch.equal(got_eps, ref_eps)
+    assert torch.equal(got_eps, ref_eps2)                # the replay really ran with t = 37
+
+
 def test_sample_schedule_list_eta_and_errors(tiny_unet):
     """ddpm.py:68-71 (explicit schedule list, unknown schedule -> TypeError) and eta > 0 (sigma * e term) with injected noise."""
     from ldm_image_generator_amd import synth
