@@ -241,9 +241,11 @@ int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, 
  * [splits][N]) receives the column sums of `a` per split: the bias gradient that goes with dW. */
 int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, long long ldb, float *out, float *colsum_a, int M, int N, int K,
                     int splits, void *stream);
-/* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) += per (slot, pixel) (atomic) */
+/* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) per (slot, pixel): accumulated
+ * atomically into a zeroed buffer when samples may share a slot, or -- unique_slots != 0: every sample has its own
+ * slot -- written once with plain stores (no zeroing needed) */
 int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, const int *slot, const float *dxf, const float *dres,
-                                 float *dx, float *dfilm, int B, int HW, int C, float eps, void *stream);
+                                 float *dx, float *dfilm, int B, int HW, int C, float eps, int unique_slots, void *stream);
 int ldm_avgpool2_bwd_f32(const float *dlo, float *dx, int B, int H, int W, int C, int accumulate, void *stream);
 int ldm_sumpool2_f32(const float *dhi, float *dlo, int B, int H, int W, int C, void *stream);         /* backward of nearest x2 */
 int ldm_stem_bwd_f32(const float *x, const float *dy, float *dw, int B, int Cin, int HW, int C0, void *stream);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void channelnorm_film_bwd_kernel(const float *
                                                                    const int *__restrict__ slot, const float *__restrict__ dxf,
                                                                    const float *__restrict__ dres, float *__restrict__ dx,
                                                                    float *__restrict__ dfilm, long long rows, int HW, int C,
-                                                                   float eps, int lpr)
+                                                                   float eps, int lpr, int unique)
 {
     const int lane = threadIdx.x & 63;
     const int rpw = 64 / lpr;
@@ -140,11 +140,18 @@ __global__ __launch_bounds__(256) void channelnorm_film_bwd_kernel(const float *
         const int c4 = sub + i * lpr;
         if (c4 < c4n) {
             const f32x4 mu = live ? fr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (live && unique) {                 // every (slot, pixel) row belongs to exactly one sample: plain 16-byte stores
+                f32x4 gm;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gm[e] = g[i][e] * ((v[i][e] - mean) / den);
+                *(f32x4 *)(dfilm + frow + 4 * c4) = gm;
+                *(f32x4 *)(dfilm + frow + C + 4 * c4) = g[i];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xn = (v[i][e] - mean) / den;
                 const float gx = g[i][e];
-                if (live) {
+                if (live && !unique) {
                     atomicAdd(dfilm + frow + 4 * c4 + e, gx * xn);
                     atomicAdd(dfilm + frow + C + 4 * c4 + e, gx);
                 }
@@ -648,7 +655,7 @@ extern "C" int ldm_reduce_partials_f32(const float *parts, float *out, int S, lo
 }
 
 extern "C" int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, const int *slot, const float *dxf, const float *dres,
-                                            float *dx, float *dfilm, int B, int HW, int C, float eps, void *stream)
+                                            float *dx, float *dfilm, int B, int HW, int C, float eps, int unique_slots, void *stream)
 {
     LDM_REQUIRE(x && film && dxf && dx && dfilm, "ldm_channelnorm_film_bwd_f32: null pointer");
     LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_bwd_f32: bad shape");
@@ -656,7 +663,7 @@ extern "C" int ldm_channelnorm_film_bwd_f32(const float *x, const float *film, c
     const long long rows = (long long)B * HW;
     const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
     hipLaunchKernelGGL(channelnorm_film_bwd_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, dxf, dres,
-                       dx, dfilm, rows, HW, C, eps, lpr);
+                       dx, dfilm, rows, HW, C, eps, lpr, unique_slots);
     LDM_CHECK_LAUNCH("ldm_channelnorm_film_bwd_f32");
     return LDM_OK;
 }

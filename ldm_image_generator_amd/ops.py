@@ -268,9 +268,9 @@ def reduce_partials(parts, S, n, out):
     return out
 
 
-def channelnorm_film_bwd(x, film, slot, dxf, dres, dx, dfilm, B, HW, C, eps=1e-4):
+def channelnorm_film_bwd(x, film, slot, dxf, dres, dx, dfilm, B, HW, C, eps=1e-4, unique_slots=False):
     _call("ldm_channelnorm_film_bwd_f32", _dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32), _dev(dxf, "dxf"),
-          _opt(dres, "dres"), _dev(dx, "dx"), _dev(dfilm, "dfilm"), B, HW, C, eps)
+          _opt(dres, "dres"), _dev(dx, "dx"), _dev(dfilm, "dfilm"), B, HW, C, eps, int(unique_slots))
     return dx
 
 

@@ -253,9 +253,9 @@ def block_backward(sv, dy, ctx, grads):
     grads.add(blk.conv.bias, bias_dy.clone())
     # ---- ChannelNorm + FiLM, residual -------------------------------------------------------------------
     film = sv["film"]
-    dfilm = torch.zeros_like(film)
+    dfilm = torch.empty_like(film) if ctx.unique_slots else torch.zeros_like(film)
     dx = torch.empty_like(x)
-    ops.channelnorm_film_bwd(x, film, ctx.slot, dxf, dy, dx, dfilm, b, h * w, c, blk.norm.eps)
+    ops.channelnorm_film_bwd(x, film, ctx.slot, dxf, dy, dx, dfilm, b, h * w, c, blk.norm.eps, unique_slots=ctx.unique_slots)
     encodings_backward(blk.encodings, sv["codes"], sv["enc_hidden"], dfilm, grads)
     return dx
 
@@ -301,7 +301,7 @@ class UNetFunction(torch.autograd.Function):
         from .unet import TimeContext
         b, cin, h, w = x.shape
         dev = x.device
-        ctx = TimeContext(time, b, dev)
+        ctx = TimeContext(time, b, dev, dedupe=False)
         order = [blk for l in net.encoder_stages for blk in l.stage.blocks] + [blk for l in net.decoder_stages for blk in l.stage.blocks]
         decisions = {blk: blk.draw() for blk in order}
         tape = []

@@ -30,8 +30,16 @@ class TimeContext:
     """Per-forward bookkeeping: distinct timesteps, sample->slot map, and the
     sin/cos code table of every (C, H, W) seen so far (shared by all blocks of a level)."""
 
-    def __init__(self, time, batch, device, uniform=None):
-        if uniform is not None:
+    def __init__(self, time, batch, device, uniform=None, dedupe=True):
+        self.unique_slots = False
+        if not dedupe:
+            # training: one slot per sample, no dedupe and no host sync -- the FiLM gradient of a (slot, pixel) row then
+            # has exactly one writer (plain stores instead of atomics); samples that happen to share a timestep simply
+            # carry identical code rows, and their gradients meet in the weight-gradient sums
+            self.t_unique = time.detach().to(device=device, dtype=torch.int64)
+            self.slot = torch.arange(batch, dtype=torch.int32, device=device)
+            self.unique_slots = True
+        elif uniform is not None:
             # (value, 1-element int64 device tensor): no host->device copy (= stream sync) inside the denoise loop
             self.t_unique = uniform[1] if isinstance(uniform, tuple) else torch.tensor([int(uniform)], dtype=torch.int64, device=device)
             self.slot = None

@@ -63,6 +63,18 @@ def test_backward_kernels_against_autograd(gpu_device):
     ops.channelnorm_film_bwd(x.detach().cuda(), film.detach().cuda(), slot.int().cuda(), dxf.cuda(), dres.cuda(), dx, dfilm, B, HW, C)
     assert rel_l2(dx.cpu(), x.grad + dres) < 1e-5
     assert rel_l2(dfilm.cpu(), film.grad) < 1e-5
+    # one slot per sample (the training path): plain stores into an UNINITIALISED buffer, no atomics
+    film3 = torch.randn(B * HW, 2 * C, generator=g).requires_grad_()
+    x.grad = None
+    f3 = film3.reshape(B, HW, 2 * C)
+    (xn.detach() * 0 + O.channel_norm(x.reshape(B, HW, C).permute(0, 2, 1).reshape(B, C, HW, 1)).reshape(B, C, HW).permute(0, 2, 1)
+     * f3[:, :, :C] + f3[:, :, C:]).backward(dxf.reshape(B, HW, C))
+    dx3 = torch.empty(B * HW, C, device=gpu_device)
+    dfilm3 = torch.full((B * HW, 2 * C), float("nan"), device=gpu_device)
+    ops.channelnorm_film_bwd(x.detach().cuda(), film3.detach().cuda(), torch.arange(B, dtype=torch.int32).cuda(), dxf.cuda(), dres.cuda(), dx3,
+                             dfilm3, B, HW, C, unique_slots=True)
+    assert rel_l2(dx3.cpu(), x.grad + dres) < 1e-5
+    assert rel_l2(dfilm3.cpu(), film3.grad) < 1e-5
     # gate / relu / pooling / colsum / l1
     a, b, dh = (torch.randn(64, 96, generator=g) for _ in range(3))
     da, db = torch.empty(64, 96, device=gpu_device), torch.empty(64, 96, device=gpu_device)
