@@ -25,7 +25,7 @@ struct TnP {
     const float *a, *b;
     float *out, *colsum;      // colsum: optional [splits][N] column sums of A (the bias gradient that goes with dW)
     long long lda, ldb;
-    int M, N, K, ms;          // ms = rows per split
+    int M, N, K, ms, splits;  // ms = rows per split
     int ntn, ntk;
 };
 
@@ -42,7 +42,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnP p)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int tile = (int)blockIdx.x % (p.ntn * p.ntk), split = (int)blockIdx.x / (p.ntn * p.ntk);
+    // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch).  All tiles of one split read the same rows of
+    // A and B, so they are given ids b, b + 8, b + 16, ... -- same XCD, consecutive dispatch waves -- and share its L2
+    const int T = p.ntn * p.ntk;
+    int tile, split;
+    if (p.splits % 8 == 0) {
+        const int b = (int)blockIdx.x, blk = b / (8 * T), in = b - blk * 8 * T;
+        split = blk * 8 + (in & 7);
+        tile = in >> 3;
+    } else {
+        tile = (int)blockIdx.x % T;
+        split = (int)blockIdx.x / T;
+    }
     const int n0 = (tile / p.ntk) * BT, k0 = (tile % p.ntk) * BT;
     const long long row0 = (long long)split * p.ms;
     const int nsteps = p.ms / BR;
@@ -133,7 +144,7 @@ extern "C" int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, lo
                     (((size_t)colsum_a) & 7) == 0,
                 "ldm_gemm_tn_f32: operands must be 16-byte addressable (lda=%lld ldb=%lld)", lda, ldb);
     TnP p{};
-    p.a = a; p.b = b; p.out = out; p.colsum = colsum_a; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.ms = M / splits;
+    p.a = a; p.b = b; p.out = out; p.colsum = colsum_a; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.ms = M / splits; p.splits = splits;
     p.ntn = N / BT; p.ntk = K / BT;
     const long long blocks = (long long)p.ntn * p.ntk * splits;
     LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_gemm_tn_f32: grid too large");
