@@ -256,6 +256,11 @@ int ldm_l1_loss_f32(const float *pred, const float *target, long long n, float *
 int ldm_l1_loss_bwd_f32(const float *pred, const float *target, const float *gscale, float *grad, long long n, void *stream);
 /* transposed im2col of the grouped 3x3 conv input: out[g][tap*32+ci][m] (weight gradient of unet.py:30) */
 int ldm_im2col3x3_t_f32(const float *x, float *out, int B, int H, int W, int C, void *stream);
+/* weight gradient of the grouped 3x3 conv (32 in / 32 out per group; autograd of unet.py:30,44) straight from the
+ * row-major activations: out_planes[(s * 4 + w)][C][288] (288 = tap * 32 + ci, the forward's weight layout), s < splits,
+ * w < 4 -- the caller sums the 4 * splits planes (ldm_reduce_partials_f32).  B*H*W must split into `splits` runs of a
+ * multiple of 128 pixels; 2 <= W <= 96. */
+int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *out_planes, int B, int H, int W, int C, int splits, void *stream);
 /* backward of ldm_window_attention_f32: dqkv [B,H,W,3C]; gradients of zero-padded tokens' k, v go to dbias_pad [3C] */
 int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
                                  float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream);

@@ -413,6 +413,99 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
     for (int e = 0; e < 16; ++e) obase_prev[((e & 3) + 8 * (e >> 2)) * ldo_e] = outv[e];
 }
 
+// ---- weight gradient ------------------------------------------------------------------------------------------------
+// dW[g][co][tap][ci] = sum over pixels m of dy[m][32 g + co] * x[nbr(m, tap)][32 g + ci]  (autograd of unet.py:30,44).
+// A "TN" MFMA problem per group: both operands have the contraction (the pixels) on their rows.  A workgroup owns one
+// group and a run of pixels; per 128-pixel tile it loads the x block with halo and the dy block into LDS (rows as they
+// lie in memory), and each wave walks its 32 pixels two at a time: ONE dy value per lane (row = co) against NINE x
+// values (column = ci, the nine neighbours; an out-of-image neighbour reads the zero row) -> nine independent
+// accumulator tiles, one per tap.  No transposed im2col copy (9x the activation), no per-group launches.
+// Each wave writes its own partial plane: out[(split * 4 + wave)][C][288]; the caller sums the planes in fixed order.
+constexpr int WG_BM = 128;
+
+__global__ __launch_bounds__(256, 2) void gconv3x3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                                float *__restrict__ out, int M, int H, int W, int C, int ms,
+                                                                float inv_w, float inv_h)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int g = (int)blockIdx.x, split = (int)blockIdx.y;
+    const int NP = WG_BM + 2 * W + 2;
+    const int NPp = (NP + 7) & ~7;
+    float *Zs = lds, *Xs = lds + 32, *Ds = Xs + NPp * 32;       // zero row | x block [NPp][32] | dy block [128][32]
+    if (t < 8) *(f32x4 *)(Zs + t * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+
+    const float *xg = x + g * 32, *dg = dy + g * 32;
+    const int row_lo = split * ms;
+#pragma unroll 1
+    for (int m0 = row_lo; m0 < row_lo + ms; m0 += WG_BM) {
+        __syncthreads();                                       // everyone is done with the previous tile's blocks
+        for (int k = wave; k < NPp / 8; k += 4) {             // x block: 8 slots (1 KiB) per DMA instruction
+            const int slot = 8 * k + (lane >> 3);
+            int m = m0 - W - 1 + slot;
+            m = m < 0 ? 0 : (m < M ? m : M - 1);
+            glds16(xg + (long long)m * C + (lane & 7) * 4, Xs + k * 256);
+        }
+        for (int k = wave; k < WG_BM / 8; k += 4)
+            glds16(dg + (long long)(m0 + 8 * k + (lane >> 3)) * C + (lane & 7) * 4, Ds + k * 256);
+        // this lane's first pixel of the tile: m0 + 32 wave + h  (then + 2 per step)
+        int px, py, row, tmp;
+        {
+            const int m = m0 + wave * 32 + h;
+            row = (int)((float)m * inv_w);
+            px = m - row * W;
+            row += px >= W ? 1 : (px < 0 ? -1 : 0);
+            px += px >= W ? -W : (px < 0 ? W : 0);
+            tmp = (int)((float)row * inv_h);
+            py = row - tmp * H;
+            py += py >= H ? -H : (py < 0 ? H : 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const unsigned xs_addr = (unsigned)(size_t)(lptr_t)Xs, ds_addr = (unsigned)(size_t)(lptr_t)Ds;
+        int slot = wave * 32 + h + W + 1;                      // own slot of the lane's current pixel
+#pragma unroll 2
+        for (int st = 0; st < 16; ++st) {
+            const float a = Ds[(wave * 32 + 2 * st + h) * 32 + r];
+            const bool up = py > 0, dn = py < H - 1, lf = px > 0, rt = px < W - 1;
+            float bv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int ddy = k / 3 - 1, ddx = k % 3 - 1;
+                const bool ok = (ddy < 0 ? up : (ddy > 0 ? dn : true)) && (ddx < 0 ? lf : (ddx > 0 ? rt : true));
+                const int sl = slot + ddy * W + ddx;
+                bv[k] = ok ? Xs[sl * 32 + r] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[k], acc[k], 0, 0, 0);
+            slot += 2;
+            px += 2;
+            if (px >= W) {                                     // W >= 2: at most one wrap per step
+                px -= W;
+                py += 1;
+                if (py >= H) py = 0;
+            }
+        }
+        (void)xs_addr; (void)ds_addr;
+    }
+
+    // acc[k] element e of lane (ci = r, h): row co = (e & 3) + 8 (e >> 2) + 4 h  ->  out[plane][32 g + co][32 k + ci]
+    float *ob = out + ((long long)(split * 4 + wave) * C + g * 32) * 288 + r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ob[((e & 3) + 8 * (e >> 2) + 4 * h) * 288 + 32 * k] = acc[k][e];
+}
+
 }  // namespace
 
 // Returns 1 if the problem is a 32-in / 32-out-per-group 3x3 convolution this kernel covers (and launches it), else 0.
@@ -444,4 +537,25 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
     else
         hipLaunchKernelGGL(gconv3x3_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
     return 1;
+}
+
+extern "C" int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *out_planes, int B, int H, int W, int C, int splits, void *stream)
+{
+    LDM_REQUIRE(x && dy && out_planes, "ldm_gconv3x3_wgrad_f32: null pointer");
+    LDM_REQUIRE(B > 0 && H > 0 && W >= 2 && W <= 96 && C >= 32 && C % 32 == 0, "ldm_gconv3x3_wgrad_f32: bad shape (2 <= W <= 96, C %% 32 == 0)");
+    const long long M = (long long)B * H * W;
+    LDM_REQUIRE(M < (1 << 24) && splits >= 1 && splits <= 65535 && M % ((long long)splits * WG_BM) == 0,
+                "ldm_gconv3x3_wgrad_f32: B*H*W=%lld must split into %d runs of a multiple of 128 pixels", M, splits);
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(dy), "ldm_gconv3x3_wgrad_f32: unaligned pointer");
+    const int NPp = (WG_BM + 2 * W + 2 + 7) & ~7;
+    const size_t smem = ((size_t)32 + (size_t)NPp * 32 + WG_BM * 32) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)gconv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(C / 32, splits), dim3(256), smem, (hipStream_t)stream, x, dy, out_planes, (int)M, H, W, C,
+                       (int)(M / splits), 1.0f / (float)W, 1.0f / (float)H);
+    LDM_CHECK_LAUNCH("ldm_gconv3x3_wgrad_f32");
+    return LDM_OK;
 }

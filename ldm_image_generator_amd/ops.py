@@ -15,7 +15,7 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
            "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
-           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue", "gemm_tn",
+           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue", "gemm_tn", "gconv3x3_wgrad",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
 
@@ -261,6 +261,12 @@ def gemm_tn(a, b, out, M, N, K, splits=1, lda=None, ldb=None, colsum=None):
     _call("ldm_gemm_tn_f32", _dev(a, "a"), N if lda is None else lda, _dev(b, "b"), K if ldb is None else ldb, _dev(out, "out"),
           _opt(colsum, "colsum"), M, N, K, splits)
     return out
+
+
+def gconv3x3_wgrad(x, dy, planes, B, H, W, C, splits):
+    """planes [4 * splits, C, 288]: partial weight gradients of the grouped 3x3 conv (sum them with reduce_partials)."""
+    _call("ldm_gconv3x3_wgrad_f32", _dev(x, "x"), _dev(dy, "dy"), _dev(planes, "planes"), B, H, W, C, splits)
+    return planes
 
 
 def reduce_partials(parts, S, n, out):

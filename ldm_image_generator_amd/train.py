@@ -116,6 +116,16 @@ def _tn_splits(n_out, k_out, m_red):
     return s
 
 
+def _gconv_splits(groups, m_red):
+    """Pixel splits of the grouped-conv weight-gradient kernel: fill ~512 workgroups, runs of a multiple of 128 pixels."""
+    if m_red % 128:
+        return 0
+    s = 1
+    while groups * s < 512 and m_red % (2 * s * 128) == 0 and m_red // (2 * s) >= 512 and s < 128:
+        s *= 2
+    return s
+
+
 def grad_weight_rows(dy, x, m_red):
     """dW [N, K] = dy^T x for row-major dy [M, N], x [M, K] (``_Rows``).  Wide layers go through the TN kernel with
     the operands as they lie in memory; narrow ones (tiny test nets) fall back to explicit transposes + the NT GEMM."""
@@ -200,9 +210,9 @@ def block_backward(sv, dy, ctx, grads):
     regs = sv["regs"]
     f = regs[0].a.weight.shape[0]
     dy_r, xf_r = _Rows(dy), _Rows(xf)
-    dy_t, bias_dy = dy_r.t(), dy_r.colsum()                        # the grouped conv's weight gradient needs dy^T anyway
     # ---- RandomMoE: y += sum_e c_e(a_e(xf) * relu(b_e(xf))) ----------------------------------------------
     dwc = grad_weight_rows(dy_r, _Rows(sv["hid"]), m)               # [C, 3F]
+    bias_dy = dy_r.colsum()
     dhid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
     ops.gemm(dy, m, 3 * f, c, [WT.get(_w2d(r.c.weight), r.c.weight) for r in regs], dhid)
     da = torch.empty_like(dhid)
@@ -244,11 +254,18 @@ def block_backward(sv, dy, ctx, grads):
     wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
     ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
              cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
-    xcol_t = torch.empty(g, 288, m, device=dev, dtype=torch.float32)
-    ops.im2col3x3_t(xf, xcol_t, b, h, w, c)
     dwconv = torch.empty(g, 32, 288, device=dev, dtype=torch.float32)
-    for gi in range(g):
-        dwconv[gi] = grad_weight(dy_t[gi * 32:(gi + 1) * 32], xcol_t[gi], m)
+    sp = _gconv_splits(g, m) if 2 <= w <= 96 else 0
+    if sp:                                                          # straight from the row-major activations
+        planes = torch.empty(4 * sp, c, 288, device=dev, dtype=torch.float32)
+        ops.gconv3x3_wgrad(xf, dy, planes, b, h, w, c, sp)
+        ops.reduce_partials(planes, 4 * sp, c * 288, dwconv)
+    else:                                                           # odd sizes: transposed im2col + one NT GEMM per group
+        dy_t = dy_r.t()
+        xcol_t = torch.empty(g, 288, m, device=dev, dtype=torch.float32)
+        ops.im2col3x3_t(xf, xcol_t, b, h, w, c)
+        for gi in range(g):
+            dwconv[gi] = grad_weight(dy_t[gi * 32:(gi + 1) * 32], xcol_t[gi], m)
     grads.add(blk.conv.weight, dwconv.reshape(c, 3, 3, 32).permute(0, 3, 1, 2))
     grads.add(blk.conv.bias, bias_dy.clone())
     # ---- ChannelNorm + FiLM, residual -------------------------------------------------------------------

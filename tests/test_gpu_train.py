@@ -46,6 +46,25 @@ def test_gemm_tn_weight_gradient_kernel(gpu_device, M, N, K, S):
     assert rel_l2(out.double().cpu(), (wide[:, :N].double().t() @ x.double()).cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,S", [(2, 8, 8, 64, 1), (4, 16, 16, 128, 2), (32, 4, 4, 256, 4), (1, 6, 64, 32, 1), (3, 32, 32, 64, 8)])
+def test_grouped_conv_weight_gradient_kernel(gpu_device, B, H, W, C, S):
+    """dW of the 32-per-group 3x3 conv from the row-major activations (no transposed im2col) vs autograd."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(B * H + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    wt = torch.zeros(C, 32, 3, 3, requires_grad=True)
+    torch.nn.functional.conv2d(x, wt, padding=1, groups=C // 32).backward(dy)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
+    drows = dy.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
+    planes = torch.full((4 * S, C, 288), float("nan"), device=gpu_device)
+    ops.gconv3x3_wgrad(rows, drows, planes, B, H, W, C, S)
+    dw = torch.empty(C, 288, device=gpu_device)
+    ops.reduce_partials(planes, 4 * S, C * 288, dw)
+    got = dw.cpu().reshape(C, 3, 3, 32).permute(0, 3, 1, 2)
+    assert rel_l2(got, wt.grad) < 1e-5
+
+
 def test_backward_kernels_against_autograd(gpu_device):
     from ldm_image_generator_amd import ops
     g = torch.Generator().manual_seed(0)
