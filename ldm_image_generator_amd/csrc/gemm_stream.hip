@@ -472,14 +472,15 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
         return launch_stream_w<4, 1, 1, 1, true, LDM_A_ROWS>(p, groups, st);
     }
     if (amode == LDM_A_CONV3X3) {
-        if (unit % 128 == 0) return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3>(p, groups, st);
+        if (unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512)
+            return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3>(p, groups, st);
         if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_CONV3X3>(p, groups, st);
         return launch_stream_w<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch_stream_w<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
-    // 128x128 tiles where N allows and M fills the chip: a third fewer LDS-DMA instructions per MFMA (with the wide
+    // 128x128 tiles where N allows and the tile count still fills the chip (two workgroups per CU): a third fewer LDS-DMA instructions per MFMA (with the wide
     // epilogue the instance fits two workgroups per CU without spills); measured +5-6 % at C = 256 / 512, neutral elsewhere
-    if (unit % 128 == 0 && p.M >= 1024) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS>(p, groups, st);
+    if (unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS>(p, groups, st);
     if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
     return launch_stream_w<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
 }
