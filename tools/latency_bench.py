@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 net = UNet(); net.load_state_dict(synth.fill_state_dict(net.state_dict())); net = net.to(dev)
 dec = Decoder(); dec.load_state_dict(synth.fill_state_dict(dec.state_dict())); dec = dec.to(dev)
 d = DDPM(model=net)
-for B in (1, 4, 16):
+for B in [int(v) for v in sys.argv[1:]] or (1, 4, 16):
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         z = d.sample((B, 8, 32, 32), seed=it, num_steps=50, progress=False)
