@@ -7,6 +7,10 @@ One "step" = one full pass of the hot path over one batch: 50 denoise steps (UNe
 + DDIM update) on this rank's 256 latents [256, 8, 32, 32], VAE decode to [256, 3, 256, 256]
 and (N > 1) the single all-gather of the images (BASELINE.json configs[2]/[3]).  x_T is
 already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Secondary objects on the same line (never `value`): `train_mode` (the reference-faithful sampling mode),
+`split_schedule` (GEMM schedule 2), `train_step` (BASELINE.json configs[4]: one optimisation step of train_ldm.py on
+latents [128, 8, 64, 64] per GPU, AdamW included, fp32 and bf16 operands), `cpu_baseline`.
 """
 import argparse
 import json
@@ -21,8 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 UNET_GFLOP_PER_SAMPLE_STEP = 13.74  # SURVEY.md 8(d), algorithmic minimum @ latent 32x32
 DECODE_GFLOP_PER_IMAGE = 80.586
+PROF_CLASSES = {0: "ldm_gemm_f32", 1: "ldm_gemm_tn_f32", 2: "ldm_gconv3x3_wgrad_f32", 3: "ldm_gemm_bf16", 4: "ldm_gemm_tn_bf16",
+                5: "ldm_gconv3x3_bf16"}
 
 
 def cpu_baseline(threads):
@@ -50,6 +57,15 @@ def cpu_baseline(threads):
                 sample_steps_per_sec=1.0 / t_step, decode_images_per_sec=1.0 / t_dec)
 
 
+def traffic_table():
+    """PMC-derived HBM traffic of the GEMM family (separate rocprofv3 --pmc passes: tools/traffic_summary.py); newest round first."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            return name, json.load(open(path))
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +83,10 @@ def main():
                     help="skip the secondary measurement in the reference-faithful mode (no .eval(): stochastic depth live)")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the secondary measurement under GEMM schedule 2 (bf16x3 split consumer)")
+    ap.add_argument("--no-train-step-leg", action="store_true", help="skip the training-step measurement (BASELINE cfg 5 per-GPU shape)")
+    ap.add_argument("--train-batch", type=int, default=128, help="training-step leg: samples per GPU (cfg 5: 1024 / 8)")
+    ap.add_argument("--train-latent", type=int, default=64, help="training-step leg: latent edge (512 px / 8)")
+    ap.add_argument("--train-steps", type=int, default=3, help="training-step leg: timed optimisation steps")
     args = ap.parse_args()
 
     from ldm_image_generator_amd import dist as ldist
@@ -98,17 +118,24 @@ def main():
     lo, hi = ldist.shard_bounds(gb, rank, world)
     x_t = ldist.global_noise(gb, (8, 32, 32), seed=0)[lo:hi].to(dev)
 
+    def decode(z):
+        img = dec(z)
+        return to_uint8_images(img) if args.gather == "u8" else img
+
     def one_pass(seed):
         z = ddpm.sample((B, 8, 32, 32), seed=seed, num_steps=T, x_init=x_t, progress=False)
-        img = dec(z)
-        if args.gather == "u8":
-            img = to_uint8_images(img)
-        return ldist.gather_images(img, gb, rank, world)
+        return ldist.gather_images(decode(z), gb, rank, world)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item())
 
     def measure(warmup, steps):
         """W untimed passes, then exactly K timed passes bracketed by barrier + synchronize; max over ranks."""
@@ -122,25 +149,38 @@ def main():
             out = one_pass(100 + i)
         fence()
         dt = time.perf_counter() - t0
+        abytes = ops.prof_read_bytes(-1) if rank == 0 else 0.0
         prof = ops.prof_read() if rank == 0 else (0, 0.0, 0.0)
         ops.prof_enable(False)
-        t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        return float(t_max.item()), prof, out
+        return max_over_ranks(dt), prof + (abytes,), out
 
-    dt, (launches, gemm_ms, gemm_flops), out = measure(args.warmup, args.steps)
+    # what produced `value`: the process-wide GEMM knobs as the library reports them (LDM_GEMM_VARIANT in the environment would show here)
+    knobs = {"gemm_variant": ops.gemm_variant(-1), "wide_epilogue": ops.gemm_wide_epilogue(-1)}
+    dt, (launches, gemm_ms, gemm_flops, gemm_bytes), out = measure(args.warmup, args.steps)
     finite = bool(torch.isfinite(out.float()).all().item())
 
-    # secondary leg, never the headline: the same passes under GEMM schedule 2 (fp32 operands cut exactly into three
-    # bf16 pieces, six bf16 MFMAs per product, fp32 accumulate -- DESIGN.md 3.1), with its deviation from the
-    # exact-fp32 images of the same seed
+    # N > 1, outside the timed region: rank 0 re-runs 4 samples of ANOTHER rank's shard alone (same seed -> same expert
+    # decisions) and compares them with the rows the all-gather delivered -- sharded == unsharded, sample for sample
+    shard_check = None
+    if world > 1:
+        lo1, _ = ldist.shard_bounds(gb, 1, world)
+        if rank == 0:
+            xs = ldist.global_noise(gb, (8, 32, 32), seed=0)[lo1:lo1 + 4].to(dev)
+            z = ddpm.sample((4, 8, 32, 32), seed=100 + args.steps - 1, num_steps=T, x_init=xs, progress=False)
+            alone = decode(z).double()
+            got = out[lo1:lo1 + 4].double()
+            err = float((alone - got).norm() / alone.norm().clamp_min(1e-30))
+            tol = 5e-6 if args.gather == "f32" else 2e-2
+            shard_check = {"rel_l2": err, "tolerance": tol, "ok": bool(err <= tol), "rows": [lo1, lo1 + 4],
+                           "note": "rank 0 alone vs rows gathered from rank 1 (batch 4 vs %d: other GEMM tile paths, fp32 re-association only)" % B}
+        fence()
+
     # secondary leg: what the reference's scripts actually do -- they never call .eval(), so SwinBlocks are skipped with
     # p = 0.25 during sampling too (unet.py:39); fewer FLOPs per image, hence reported beside, not as, the headline
     train_leg = None
     if not args.no_train_mode_leg and args.mode == "eval":
         net.train(True)
-        dt3, (l3, ms3, fl3), out3 = measure(1, args.steps)
+        dt3, (l3, ms3, fl3, _), out3 = measure(1, args.steps)
         net.train(False)
         train_leg = {"value": gb * args.steps / dt3, "unit": "images/s", "ms_per_step": dt3 / args.steps * 1e3,
                      "gemm_tflops": fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else None,
@@ -148,20 +188,82 @@ def main():
                      "outputs_finite": bool(torch.isfinite(out3.float()).all().item()),
                      "note": "reference-faithful train mode (stochastic depth live while sampling), same seeds"}
         del out3
+    # secondary leg, never the headline: the same passes under GEMM schedule 2 (fp32 operands cut exactly into three
+    # bf16 pieces, six bf16 MFMAs per product, fp32 accumulate -- DESIGN.md 3.1), with its deviation from the
+    # exact-fp32 images of the same seed
     split = None
     if not args.no_split_leg:
         keep = out[: min(16, out.shape[0])].clone()
         del out
         old = ops.gemm_variant(2)
-        dt2, (l2, ms2, fl2), out2 = measure(1, args.steps)
+        dt2, (l2, ms2, fl2, _), out2 = measure(1, args.steps)
         ops.gemm_variant(old)
         d = (out2[: keep.shape[0]].double() - keep.double())
+        eq = fl2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else None
         split = {"value": gb * args.steps / dt2, "unit": "images/s", "ms_per_step": dt2 / args.steps * 1e3,
-                 "gemm_tflops_fp32_equivalent": fl2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else None,
+                 "gemm_tflops_fp32_equivalent": eq,
+                 "roofline": None if eq is None else {"bound": "mfma", "achieved": eq, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s",
+                                                      "frac": eq / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+                                                      "note": "peak = dense bf16 MFMA / 6 (six bf16 products per fp32 product)"},
                  "rel_l2_vs_exact_images": float(d.norm() / keep.double().norm()),
                  "note": "GEMM schedule 2: v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits of the fp32 operands, "
                          "fp32 accumulate; opt-in, not the headline"}
         del out2
+    else:
+        del out
+
+    # BASELINE.json configs[4]: one optimisation step of train_ldm.py:76-86 at the per-GPU shape of "global batch 1024 over
+    # 8 GPUs, 512x512 -> latents [128, 8, 64, 64]": q-sample, UNet forward with the tape, L1 loss, hand-written backward,
+    # (N > 1) the gradient all-reduce, AdamW.  Random-init formula weights, train mode (stochastic depth live), synthetic latents.
+    train_step = None
+    if not args.no_train_step_leg:
+        from ldm_image_generator_amd import train as ltrain
+        torch.cuda.empty_cache()
+        net.train(True)
+        opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)                       # train_ldm.py:67
+        xb = torch.randn(args.train_batch, 8, args.train_latent, args.train_latent,
+                         generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+        train_step = {"unit": "samples/s", "config": {"workload": "train_ldm step, latents [%d, 8, %d, %d] per GPU, UNet(385.7M) train mode, "
+                                                                  "L1 loss, AdamW" % (args.train_batch, args.train_latent, args.train_latent),
+                                                      "global_batch": args.train_batch * world, "steps": args.train_steps, "warmup": 1}}
+        for prec in getattr(ltrain, "PRECISIONS", ("f32",)):
+            ltrain.set_precision(net, prec) if hasattr(ltrain, "set_precision") else None
+            torch.cuda.reset_peak_memory_stats()
+            ldist.train_step(ddpm, opt, xb, 0, world)                              # warm-up: allocator, RCCL buffers, weight caches
+            fence()
+            ops.prof_enable(rank == 0)
+            t0 = time.perf_counter()
+            for i in range(args.train_steps):
+                loss = ldist.train_step(ddpm, opt, xb, 1 + i, world)
+            fence()
+            dts = max_over_ranks(time.perf_counter() - t0)
+            leg = {"ms_per_step": dts / args.train_steps * 1e3, "value": args.train_batch * world * args.train_steps / dts,
+                   "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            if rank == 0:
+                per, tot_ms, tot_fl = {}, 0.0, 0.0
+                for cls, name in PROF_CLASSES.items():
+                    n, ms, fl = ops.prof_read_class(cls)
+                    if n:
+                        per[name] = {"launches_per_step": n // args.train_steps, "ms_per_step": ms / args.train_steps,
+                                     "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None}
+                        tot_ms += ms
+                        tot_fl += fl
+                ops.prof_read()
+                peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else FP32_MFMA_PEAK_TFLOPS
+                ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+                leg["executed_gflop_per_step"] = tot_fl / 1e9 / args.train_steps
+                leg["mfma_kernel_ms_per_step"] = tot_ms / args.train_steps
+                leg["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "kernel": "all MFMA kernels of the step (NT, TN weight-gradient, grouped-conv weight-gradient), hipEvents per launch",
+                                   "per_kernel": per}
+            ops.prof_enable(False)
+            train_step[prec] = leg
+        if hasattr(ltrain, "set_precision"):
+            ltrain.set_precision(net, "f32")
+        if "bf16" in train_step and "f32" in train_step:
+            train_step["bf16_over_f32"] = train_step["bf16"]["value"] / train_step["f32"]["value"]
+        del opt, xb
+        net.train(args.mode == "train")
 
     if rank == 0:
         images = gb * args.steps
@@ -178,22 +280,34 @@ def main():
             "denoise_steps_per_sec": images * T / dt / B, "sample_steps_per_sec": images * T / dt,
             "algorithmic_tflops": algo_flops / dt / 1e12 if args.mode == "eval" else None,
             "outputs_finite": finite,
+            "gemm_variant": knobs["gemm_variant"], "wide_epilogue": knobs["wide_epilogue"],
+            "gemm_variant_note": "1 = exact fp32 (v_mfma_f32_32x32x2_f32), the schedule `value` was measured under; 2 appears only in split_schedule",
             "roofline": {"bound": "mfma", "kernel": "ldm_gemm_f32 family (gemm_stream_kernel, gconv3x3_kernel; v_mfma_f32_32x32x2_f32), all launches of the timed region",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "launches": launches, "kernel_ms": gemm_ms, "gflop_per_sample_step_measured":
-                             None if args.mode != "eval" else gemm_flops / 1e9 / (B * args.steps) / T},
+                         "launches": launches, "kernel_ms": gemm_ms,
+                         "algorithmic_bytes_per_launch": gemm_bytes / launches if launches else None,
+                         "gflop_per_sample_step_measured": None if args.mode != "eval" else gemm_flops / 1e9 / (B * args.steps) / T},
         }
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):      # PMC passes are separate runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): tools/traffic_summary.py
-            tj = json.load(open(tpath))
+        tname, tj = traffic_table()
+        if tj is not None:      # PMC passes are separate runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
             line["roofline"]["traffic"] = tj["gemm_hbm_bytes_per_launch"]
-            line["roofline"]["traffic_unit"] = "bytes per GEMM launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.md)"
-            line["roofline"]["algorithmic_bytes_per_launch"] = None
+            line["roofline"]["traffic_unit"] = "bytes per GEMM launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)" % tname.replace(".json", ".md")
+            if launches:
+                line["roofline"]["traffic_over_algorithmic"] = tj["gemm_hbm_bytes_per_launch"] / (gemm_bytes / launches)
+            for k in ("fetch_over_algorithmic", "write_over_algorithmic", "per_instance"):
+                if k in tj:
+                    line["roofline"][k] = tj[k]
+        if world > 1:
+            line["dist_world_size"] = dist.get_world_size()
+            line["dist_backend"] = dist.get_backend()
+            line["sharded_equals_unsharded"] = shard_check
         if train_leg is not None:
             line["train_mode"] = train_leg
         if split is not None:
             line["split_schedule"] = split
+        if train_step is not None:
+            line["train_step"] = train_step
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64))
         print(json.dumps(line), flush=True)

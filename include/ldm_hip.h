@@ -131,7 +131,11 @@ int ldm_gemm_wide_epilogue(int v);
  * bracketed by hipEvents on ITS stream; ldm_prof_read synchronises those events
  * and returns launches, summed kernel milliseconds and summed algorithmic FLOPs. */
 int ldm_prof_enable(int on);
-int ldm_prof_read(long long *launches, double *ms, double *flops);
+int ldm_prof_read(long long *launches, double *ms, double *flops);     /* all classes; clears the records */
+/* kernel classes: 0 ldm_gemm_f32, 1 ldm_gemm_tn_f32, 2 ldm_gconv3x3_wgrad_f32, 3 ldm_gemm_bf16, 4 ldm_gemm_tn_bf16,
+ * 5 grouped conv with bf16 operands; cls < 0 = all.  Does not clear (call ldm_prof_read last). */
+int ldm_prof_read_class(int cls, long long *launches, double *ms, double *flops);
+int ldm_prof_read_bytes(int cls, double *bytes);    /* summed algorithmic HBM bytes of the class's launches (operands once) */
 
 /* modules.py:23-25 (ChannelNorm, unbiased var, eps inside sqrt) fused with the
  * FiLM of unet.py:22.  film is [nslot, HW, 2C] (mul | bias); slot[b] selects the

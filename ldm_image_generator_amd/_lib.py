@@ -88,6 +88,8 @@ SIGNATURES = {
                                   ctypes.c_size_t, _P, _P]),
     "ldm_prof_enable": (_I, [_I]),
     "ldm_prof_read": (_I, [ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ldm_prof_read_bytes": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),
+    "ldm_prof_read_class": (_I, [_I, ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ldm_channelnorm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ldm_sincos_embed_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),

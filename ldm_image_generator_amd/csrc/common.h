@@ -10,6 +10,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void ldm_set_error(const char *fmt, ...);
 
+// hipEvent profiler (prof.cpp): kernel classes of ldm_prof_read_class
+#define LDM_PROF_GEMM      0   /* ldm_gemm_f32 (NT, exact fp32 / split schedule, grouped conv forward + data gradient) */
+#define LDM_PROF_GEMM_TN   1   /* ldm_gemm_tn_f32 (weight gradients)                                                   */
+#define LDM_PROF_GCONV_WG  2   /* ldm_gconv3x3_wgrad_f32                                                               */
+#define LDM_PROF_GEMM_BF16 3   /* ldm_gemm_bf16 (NT, v_mfma_f32_32x32x16_bf16)                                         */
+#define LDM_PROF_TN_BF16   4   /* ldm_gemm_tn_bf16                                                                     */
+#define LDM_PROF_GCONV_BF16 5  /* grouped conv, bf16 operands                                                          */
+void *ldm_prof_begin(int cls, double flops, hipStream_t st, double bytes = 0.0);      // NULL when profiling is off; bytes = algorithmic HBM bytes
+void ldm_prof_end(void *h, hipStream_t st);
+
 #define LDM_REQUIRE(cond, ...)                 \
     do {                                       \
         if (!(cond)) {                         \

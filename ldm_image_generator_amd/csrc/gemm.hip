@@ -21,8 +21,6 @@
 // 2x2 | nearest-x2 replicate), groups on grid.y.
 #include "gemm_common.h"
 #include <cstdlib>
-#include <vector>
-#include <mutex>
 
 using namespace ldmgemm;
 
@@ -164,15 +162,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p)
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct ProfRec {
-    hipEvent_t start, stop;
-    double flops;
-};
-std::mutex g_prof_mu;
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof_pool;
-size_t g_prof_used = 0;
-
 template <int WM, int WN, int TM, int TN, bool GATE, int AMODE>
 int launch(const GemmP &p, int groups, hipStream_t st)
 {
@@ -339,34 +328,6 @@ extern "C" int ldm_gemm_variant(int v)
     return old;
 }
 
-extern "C" int ldm_prof_enable(int on)
-{
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
-    g_prof_used = 0;
-    return LDM_OK;
-}
-
-extern "C" int ldm_prof_read(long long *launches, double *ms, double *flops)
-{
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    double tms = 0.0, tf = 0.0;
-    for (size_t i = 0; i < g_prof_used; ++i) {
-        float e = 0.f;
-        if (hipEventSynchronize(g_prof_pool[i].stop) != hipSuccess || hipEventElapsedTime(&e, g_prof_pool[i].start, g_prof_pool[i].stop) != hipSuccess) {
-            ldm_set_error("ldm_prof_read: event %zu not readable", i);
-            return LDM_ELAUNCH;
-        }
-        tms += e;
-        tf += g_prof_pool[i].flops;
-    }
-    if (launches) *launches = (long long)g_prof_used;
-    if (ms) *ms = tms;
-    if (flops) *flops = tf;
-    g_prof_used = 0;
-    return LDM_OK;
-}
-
 extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
 {
     LDM_REQUIRE(d != nullptr, "ldm_gemm_f32: null descriptor");
@@ -429,26 +390,15 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
     }
 
     hipStream_t st = (hipStream_t)stream;
-    ProfRec *rec = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (g_prof_on) {
-            if (g_prof_used == g_prof_pool.size()) {
-                ProfRec r{};
-                if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
-                    ldm_set_error("ldm_gemm_f32: hipEventCreate failed");
-                    return LDM_ELAUNCH;
-                }
-                g_prof_pool.push_back(r);
-            }
-            rec = &g_prof_pool[g_prof_used++];
-            rec->flops = 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0);
-            (void)hipEventRecord(rec->start, st);
-        }
-    }
+    // algorithmic HBM bytes of the launch: every operand element once (the 3x3 im2col re-reads and the x2 replicate of the
+    // addressing modes are not algorithmic), weights once per group
+    const double a_elems = (double)d->M * (d->a_mode == LDM_A_CONV3X3 ? d->Cin : d->K) * (d->a_gstride || groups == 1 ? groups : 1);
+    const double o_elems = (double)d->M * d->N * groups * (d->o_mode == LDM_O_UP2 ? 4.0 : 1.0);
+    const double algo_bytes = 4.0 * (a_elems + (double)d->N * d->K * groups * (gate ? 2.0 : 1.0) + o_elems * (d->addend ? 2.0 : 1.0));
+    void *rec = ldm_prof_begin(LDM_PROF_GEMM, 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0), st, algo_bytes);
     if (gate && d->a_mode == LDM_A_CONV3X3) { ldm_set_error("ldm_gemm_f32: GATE with conv3x3 unsupported"); return LDM_EINVAL; }
     if (!(d->workspace && splitk_launch(*d, p, gate, st))) launch_any(p, groups, gate, d->a_mode, st);
-    if (rec) (void)hipEventRecord(rec->stop, st);
+    ldm_prof_end(rec, st);
     LDM_CHECK_LAUNCH("ldm_gemm_f32");
     return LDM_OK;
 }

@@ -1,0 +1,96 @@
+// hipEvent timing of the MFMA kernels for bench.py (include/ldm_hip.h, ldm_prof_*): when enabled, every launch of a
+// profiled entry point is bracketed by two events recorded on ITS stream; reading synchronises the events and sums
+// kernel time and algorithmic FLOPs per kernel class.  Host code only.
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct ProfRec {
+    hipEvent_t start, stop;
+    double flops, bytes;
+    int cls;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<ProfRec> g_pool;
+size_t g_used = 0;
+
+}  // namespace
+
+void *ldm_prof_begin(int cls, double flops, hipStream_t st, double bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_on) return nullptr;
+    if (g_used == g_pool.size()) {
+        ProfRec r{};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return nullptr;
+        g_pool.push_back(r);
+    }
+    ProfRec *rec = &g_pool[g_used++];
+    rec->flops = flops;
+    rec->bytes = bytes;
+    rec->cls = cls;
+    (void)hipEventRecord(rec->start, st);
+    return (void *)(size_t)(g_used);          // index + 1: the pool may reallocate
+}
+
+void ldm_prof_end(void *h, hipStream_t st)
+{
+    if (!h) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t i = (size_t)h - 1;
+    if (i < g_used) (void)hipEventRecord(g_pool[i].stop, st);
+}
+
+static int prof_sum(int cls, long long *launches, double *ms, double *flops, double *bytes = nullptr)
+{
+    double tms = 0.0, tf = 0.0, tb = 0.0;
+    long long n = 0;
+    for (size_t i = 0; i < g_used; ++i) {
+        if (cls >= 0 && g_pool[i].cls != cls) continue;
+        float e = 0.f;
+        if (hipEventSynchronize(g_pool[i].stop) != hipSuccess || hipEventElapsedTime(&e, g_pool[i].start, g_pool[i].stop) != hipSuccess) {
+            ldm_set_error("ldm_prof_read: event %zu not readable", i);
+            return LDM_ELAUNCH;
+        }
+        tms += e;
+        tf += g_pool[i].flops;
+        tb += g_pool[i].bytes;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (ms) *ms = tms;
+    if (flops) *flops = tf;
+    if (bytes) *bytes = tb;
+    return LDM_OK;
+}
+
+extern "C" int ldm_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    g_used = 0;
+    return LDM_OK;
+}
+
+extern "C" int ldm_prof_read_class(int cls, long long *launches, double *ms, double *flops)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return prof_sum(cls, launches, ms, flops);
+}
+
+extern "C" int ldm_prof_read_bytes(int cls, double *bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return prof_sum(cls, nullptr, nullptr, nullptr, bytes);
+}
+
+extern "C" int ldm_prof_read(long long *launches, double *ms, double *flops)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int rc = prof_sum(-1, launches, ms, flops);
+    g_used = 0;
+    return rc;
+}

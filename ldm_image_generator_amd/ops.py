@@ -14,7 +14,7 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
                    GemmDesc)
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
-           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
+           "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "prof_read_class", "prof_read_bytes", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
            "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue", "gemm_tn", "gconv3x3_wgrad",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
@@ -216,6 +216,19 @@ def prof_read():
     n, ms, fl = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
     _lib.check(_lib.load().ldm_prof_read(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "ldm_prof_read")
     return n.value, ms.value, fl.value
+
+
+def prof_read_class(cls):
+    """(launches, kernel ms, algorithmic FLOPs) of one kernel class (see ldm_prof_read_class); does not clear."""
+    n, ms, fl = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
+    _lib.check(_lib.load().ldm_prof_read_class(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "ldm_prof_read_class")
+    return n.value, ms.value, fl.value
+
+
+def prof_read_bytes(cls=-1):
+    b = ctypes.c_double(0)
+    _lib.check(_lib.load().ldm_prof_read_bytes(cls, ctypes.byref(b)), "ldm_prof_read_bytes")
+    return b.value
 
 
 # ---- training-step entry points (include/ldm_hip.h, "Training step") ---------------------------------

@@ -264,6 +264,67 @@ def loss_cases(tiny):
         p.grad = None
 
 
+def loss_full_cases():
+    """Training parity at FULL width (cfg 5): default UNet() (385.7 M parameters, C = 128..1024), formula weights,
+    latents [2, 8, 64, 64] (121-window attention at stage 0) and [2, 8, 32, 32]; fixed t / e / Python-random seed.
+    Stored: loss, every per-parameter gradient norm (-1 where autograd leaves None) and a few small gradient tensors."""
+    full = load_formula(ref_unet.UNet())
+    full.train()
+    d = ref_ddpm.DDPM(model=full)
+    arrs = {}
+    for tag, res, seed in (("r64", 64, 5), ("r32", 32, 6)):
+        x = g("lossfull.x.%d" % res, (2, 8, res, res))
+        torch.manual_seed(seed)
+        random.seed(seed)
+        st = torch.get_rng_state()
+        t = torch.randint(low=1, high=1000, size=(2,))
+        e = torch.randn(2, 8, res, res)
+        torch.set_rng_state(st)
+        for p in full.parameters():
+            p.grad = None
+        with Trace() as tr:
+            loss = d.calculate_loss(x)
+        loss.backward()
+        arrs.update({"x_" + tag: x, "t_" + tag: t, "e_" + tag: e, "loss_" + tag: loss.detach(), "trace_" + tag: tr.encoded()})
+        names, norms = [], []
+        sd_grads = {}
+        for k, p in full.named_parameters():
+            names.append(k)
+            norms.append(-1.0 if p.grad is None else float(p.grad.double().norm()))
+            sd_grads[k] = p.grad
+        arrs["grad_names"] = np.asarray(names)
+        arrs["grad_norms_" + tag] = np.asarray(norms)
+        arrs["grad_encoder_first_weight_" + tag] = full.encoder_first.weight.grad
+        arrs["grad_decoder_last_weight_" + tag] = full.decoder_last.weight.grad
+        # small slices of large gradients that exist in this draw (first executed block of each kind)
+        def first(pred):
+            for k in names:
+                if pred(k) and sd_grads[k] is not None:
+                    return k
+            return None
+        picks = {
+            "expert_c1024": first(lambda k: k.startswith("encoder_stages.3") and ".ffn.experts." in k and k.endswith(".c.weight")),
+            "general_a128": first(lambda k: k.startswith("decoder_stages.3") and ".ffn.general.a.weight" in k),
+            "in_proj": first(lambda k: k.endswith("self_attention.attention.in_proj_weight") and k.startswith("decoder_stages.3")),
+            "in_proj_bias": first(lambda k: k.endswith("self_attention.attention.in_proj_bias") and k.startswith("decoder_stages.2")),
+            "gconv512": first(lambda k: k.startswith("encoder_stages.2") and k.endswith(".conv.weight")),
+            "gconv128": first(lambda k: k.startswith("decoder_stages.3") and k.endswith(".conv.weight")),
+            "proj1": first(lambda k: k.startswith("encoder_stages.0") and k.endswith("encodings.proj1.weight")),
+            "down1": "encoder_stages.1.ch_conv.0.weight",
+            "up2": "decoder_stages.2.ch_conv.1.weight",
+        }
+        for nick, k in picks.items():
+            if k is None:
+                continue
+            gk = sd_grads[k]
+            sl = gk.reshape(gk.shape[0], -1)[:64, :96] if gk.ndim > 1 else gk[:256]
+            arrs["gslice_%s_%s" % (nick, tag)] = sl
+            arrs["gslice_%s_%s_key" % (nick, tag)] = np.asarray(k)
+        for p in full.parameters():
+            p.grad = None
+    save("loss_full", **arrs)
+
+
 @torch.no_grad()
 def vae_cases():
     rb = load_formula(ref_vae.ResBlock(32))
@@ -292,6 +353,9 @@ def encoder_cases():
 
 
 if __name__ == "__main__":
+    if "--loss-full-only" in sys.argv:
+        loss_full_cases()
+        sys.exit(0)
     if "--encoder-only" in sys.argv:
         encoder_cases()
         sys.exit(0)
@@ -301,5 +365,6 @@ if __name__ == "__main__":
     tiny, full = unet_cases()
     sample_cases(tiny, full)
     loss_cases(tiny)
+    loss_full_cases()
     vae_cases()
     encoder_cases()

@@ -185,13 +185,15 @@ def test_sincos_embed_matches_reference_tables(gpu_device):
     for c, h, w in [(32, 7, 5), (128, 32, 32), (1024, 4, 4)]:
         emb = sinusoidal.embed(steps.cuda(), h, w, c).cpu().reshape(50, h * w, 2 * c)
         pe = T(g["pe_%d_%d_%d" % (c, h, w)]).permute(1, 2, 0).reshape(h * w, c)
-        assert (emb[0, :, :c] - pe).abs().max() < 2e-6
+        assert (emb[0, :, :c] - pe).abs().max() < 2.4e-7
         assert torch.equal(emb[0, :, :c], emb[49, :, :c])
         if "te_%d" % c in g:
             te = T(g["te_%d" % c])
-            # arguments reach ~3.1e3 rad: one ulp of the argument is 2.4e-4
-            assert (emb[:, 0, c:] - te).abs().max() < 5e-4
-            assert (emb[:, 0, c:] - te).abs().mean() < 2e-5
+            # the argument (float(t) * pi_f32) * f is formed in the reference's order from host-computed frequencies, so it is
+            # bit-identical; device sinf/cosf and torch's CPU sin/cos then differ by at most one ulp of the RESULT
+            # (measured on MI355X, tools/sincos_err.py: max 5.96e-8, 81 % of the values bit-equal)
+            assert (emb[:, 0, c:] - te).abs().max() < 2.4e-7
+            assert (emb[:, 0, c:] - te).abs().mean() < 3e-8
             assert torch.equal(emb[:, 0, c:], emb[:, h * w - 1, c:])
 
 

@@ -235,3 +235,103 @@ def test_unet_gradients_vs_oracle_autograd(gpu_device):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         assert rel_l2(p.grad.cpu(), ref) < 1e-4, k
+
+
+# ------------------------------------------------------------------------------------------------------
+# FULL width (BASELINE cfg 5: default UNet(), C = 128..1024): the routes the tiny nets never take -- TN weight-gradient
+# kernel with fused column sums and its split choice, the grouped-conv weight-gradient kernel, 121-window attention
+# backward at R = 64, one FiLM slot per sample -- against the reference's own autograd (tests/golden/loss_full.npz).
+# ------------------------------------------------------------------------------------------------------
+def _full_step(net, d, g, tag, seed):
+    from ldm_image_generator_amd import ops
+    from ldm_image_generator_amd.train import L1LossFunction
+    x, t, e = T(g["x_" + tag]).cuda(), T(g["t_" + tag]), T(g["e_" + tag]).cuda()
+    ab = d.alpha_bar[t]
+    xt = torch.empty_like(x)
+    ops.qsample(x, e, torch.sqrt(ab).cuda(), torch.sqrt(1 - ab).cuda(), xt)
+    for p in net.parameters():
+        p.grad = None
+    random.seed(seed)
+    e_theta = net(x=xt, time=t.cuda(), condition=None)
+    loss = L1LossFunction.apply(e_theta, e)
+    loss.backward()
+    return loss
+
+
+@pytest.fixture(scope="module")
+def full_net(gpu_device):
+    from ldm_image_generator_amd.unet import UNet
+    return formula(UNet()).train()
+
+
+@pytest.mark.parametrize("tag,seed", [("r64", 5), ("r32", 6)])
+def test_full_width_training_step_matches_reference_gradients(gpu_device, full_net, tag, seed):
+    from ldm_image_generator_amd.ddpm import DDPM
+    g = load_golden("loss_full")
+    net = full_net
+    d = DDPM(model=net)
+    loss = _full_step(net, d, g, tag, seed)
+    ref_loss = float(g["loss_" + tag])
+    assert abs(float(loss.detach()) - ref_loss) < 1e-5 * abs(ref_loss)
+    names = [str(n) for n in g["grad_names"]]
+    norms = dict(zip(names, g["grad_norms_" + tag]))
+    worst, n_used = 0.0, 0
+    for k, p in net.named_parameters():
+        ref = norms[k]
+        if ref < 0:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        n_used += 1
+        got = float(p.grad.double().norm())
+        err = abs(got - ref) / max(ref, 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-4, (k, got, ref)
+    assert n_used > 500
+    print("full-width %s: %d used parameters, worst gradient-norm deviation %.2e" % (tag, n_used, worst))
+    grads = dict(net.named_parameters())
+    assert rel_l2(net.encoder_first.weight.grad.cpu(), T(g["grad_encoder_first_weight_" + tag])) < 1e-4
+    assert rel_l2(net.decoder_last.weight.grad.cpu(), T(g["grad_decoder_last_weight_" + tag])) < 1e-4
+    checked = 0
+    for key in g:
+        if key.startswith("gslice_") and key.endswith("_" + tag) and not key.endswith("_key"):
+            pname = str(g[key + "_key"])
+            gk = grads[pname].grad
+            sl = gk.reshape(gk.shape[0], -1)[:64, :96] if gk.ndim > 1 else gk[:256]
+            assert rel_l2(sl.cpu(), T(g[key])) < 1e-4, (key, pname)
+            checked += 1
+    assert checked >= 6
+
+
+def test_full_width_batch_step_equals_mean_of_half_batches(gpu_device, full_net):
+    """Size-independent property of the training step (mean-reduced L1 loss, no batch statistics anywhere): the
+    gradients of a batch are the average of the gradients of its two halves under the same expert / depth decisions."""
+    from ldm_image_generator_amd import ops
+    from ldm_image_generator_amd.train import L1LossFunction
+    net = full_net
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(8, 8, 32, 32, generator=gen).cuda()
+    e = torch.randn(8, 8, 32, 32, generator=gen).cuda()
+    t = torch.randint(1, 1000, (8,), generator=gen).cuda()
+
+    def run(sl):
+        for p in net.parameters():
+            p.grad = None
+        random.seed(77)
+        loss = L1LossFunction.apply(net(x=x[sl], time=t[sl], condition=None), e[sl])
+        loss.backward()
+        return float(loss), {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}
+
+    l_all, g_all = run(slice(0, 8))
+    l_a, g_a = run(slice(0, 4))
+    l_b, g_b = run(slice(4, 8))
+    assert abs(l_all - 0.5 * (l_a + l_b)) < 1e-5 * abs(l_all)
+    worst = 0.0
+    for k, ga in g_all.items():
+        if ga is None:
+            assert g_a[k] is None and g_b[k] is None, k
+            continue
+        err = rel_l2(0.5 * (g_a[k] + g_b[k]), ga)
+        worst = max(worst, err)
+        assert err < 2e-4, (k, err)
+    print("half-batch property: worst rel-L2 %.2e" % worst)
