@@ -269,6 +269,35 @@ int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *out_planes, i
 int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
                                  float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 training step (BASELINE.json configs[4]: "train_ldm.py ... bf16 ... fwd+bwd HIP kernels"; the reference
+ * trains under reduced-precision autocast with fp32 master weights, train_ldm.py:68,80).  GEMM operands are rounded
+ * ONCE to bf16 (round-to-nearest-even) by their producers; products accumulate in fp32 (v_mfma_f32_32x32x16_bf16);
+ * the residual stream, FiLM rows, every parameter gradient and the optimizer stay fp32.  bf16 buffers travel as
+ * `void *` (2 bytes per element, the high half of the fp32 encoding).
+ * ------------------------------------------------------------------------------------------------ */
+/* ldm_gemm_f32's descriptor with bf16 operands: d->a, d->w[s] point to bf16; d->lda, d->ldw, d->K, K-segment lengths and
+ * the a/w group strides count bf16 elements (K, N multiples of 64; rows 16-byte addressable).  bias / addend are fp32.
+ * out_bf16 == 0: d->out is fp32 [M, ldo];  != 0: d->out is bf16 [M, ldo] (no addend).  Rows in / rows out only, no gate. */
+int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream);
+/* weight gradient from bf16 operands as they lie in memory (ldm_gemm_tn_f32's contract; M / splits a multiple of 64):
+ * out[s][n][k] fp32 = sum over the rows m of split s of a[m*lda + n] * b[m*ldb + k]; colsum_a optional [splits][N] fp32. */
+int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, long long ldb, float *out, float *colsum_a, int M, int N, int K, int splits,
+                     void *stream);
+int ldm_cast_bf16(const float *x, void *out, long long n, void *stream);                       /* out = bf16(x), n % 4 == 0          */
+int ldm_uncast_bf16(const void *x, float *out, long long n, void *stream);                      /* out = fp32(x), exact               */
+int ldm_transpose_cast_bf16(const float *x, void *out, long long R, int C, void *stream);      /* out[C][R] = bf16(x[R][C]^T)        */
+int ldm_gate_fwd_bf16(const void *a, const void *b, void *out, long long n, void *stream);     /* a * relu(b), all bf16, n % 8 == 0  */
+int ldm_gate_bwd_bf16(const void *dh, const void *a, const void *b, void *da, void *db, long long n, void *stream);
+int ldm_relu_bwd_bf16(const void *dy, const void *y, void *dx, long long n, void *stream);
+/* ldm_channelnorm_film_f32 with the result written as fp32 and / or bf16 (either output may be NULL) */
+int ldm_channelnorm_film_bf16(const float *x, const float *film, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
+                              void *stream);
+/* ldm_channelnorm_film_bwd_f32 for one FiLM slot per sample: dx fp32 (+ optional bf16 copy for the GEMMs that consume it),
+ * dfilm (mul | bias) [B*HW, 2C] written once as bf16 */
+int ldm_channelnorm_film_bwd_bf16(const float *x, const float *film, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
+                                  void *dfilm_bf16, int B, int HW, int C, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

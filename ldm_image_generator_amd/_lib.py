@@ -121,6 +121,17 @@ SIGNATURES = {
     "ldm_l1_loss_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P]),
     "ldm_im2col3x3_t_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_window_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    # bf16 training step
+    "ldm_gemm_bf16": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
+    "ldm_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_cast_bf16": (_I, [_P, _P, _L, _P]),
+    "ldm_uncast_bf16": (_I, [_P, _P, _L, _P]),
+    "ldm_transpose_cast_bf16": (_I, [_P, _P, _L, _I, _P]),
+    "ldm_gate_fwd_bf16": (_I, [_P, _P, _P, _L, _P]),
+    "ldm_gate_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    "ldm_relu_bwd_bf16": (_I, [_P, _P, _P, _L, _P]),
+    "ldm_channelnorm_film_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_channelnorm_film_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
 }
 
 _lib = None

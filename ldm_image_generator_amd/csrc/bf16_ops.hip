@@ -1,0 +1,329 @@
+// HBM-bound kernels of the bf16 training step (BASELINE cfg 5): the producers that round GEMM operands ONCE to bf16, and the
+// elementwise pieces whose inputs and outputs are all GEMM operands.  16-byte accesses per lane (8 bf16 / 4 fp32), wave-shuffle
+// reductions, fp32 arithmetic inside.  The residual stream, its gradient, FiLM rows and all parameter gradients stay fp32.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxV = 8;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi)          // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
+{
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float lo16(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ u32x2 pack4(const f32x4 &v) { return u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}; }
+
+__device__ __forceinline__ float group_sum(float v, int lpr)
+{
+    for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+inline int pow2_lanes(int c4n)
+{
+    int lpr = 1;
+    while (lpr < c4n && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+// ---- casts ---------------------------------------------------------------------------------------------------------------
+__global__ void cast_bf16_kernel(const f32x4 *__restrict__ x, u32x2 *__restrict__ out, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) out[i] = pack4(x[i]);
+}
+
+__global__ void uncast_bf16_kernel(const u32x2 *__restrict__ x, f32x4 *__restrict__ out, long long n4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const u32x2 v = x[i];
+    out[i] = f32x4{lo16(v[0]), hi16(v[0]), lo16(v[1]), hi16(v[1])};
+}
+
+// out[c][r] = bf16(x[r][c]): 64 x 64 tiles through LDS (padded rows), coalesced on both sides
+__global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ out, long long R, int C)
+{
+    __shared__ float tile[64][65];
+    const long long r0 = (long long)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const long long r = r0 + i;
+        const int c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? x[r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i;
+        const long long r = r0 + tx;
+        if (c < C && r < R) out[(long long)c * R + r] = (unsigned short)(pack2(tile[tx][i], 0.f) & 0xFFFFu);
+    }
+}
+
+// ---- gate / relu, all operands bf16 ------------------------------------------------------------------------------------------
+// hid = a * relu(b)   (modules.py:15), 8 elements per lane
+__global__ void gate_fwd_bf16_kernel(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, u32x4 *__restrict__ out, long long n8)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 av = a[i], bv = b[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2(lo16(av[e]) * fmaxf(lo16(bv[e]), 0.f), hi16(av[e]) * fmaxf(hi16(bv[e]), 0.f));
+    out[i] = o;
+}
+
+__global__ void gate_bwd_bf16_kernel(const u32x4 *__restrict__ dh, const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, u32x4 *__restrict__ da,
+                                     u32x4 *__restrict__ db, long long n8)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 g = dh[i], av = a[i], bv = b[i];
+    u32x4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float g0 = lo16(g[e]), g1 = hi16(g[e]), a0 = lo16(av[e]), a1 = hi16(av[e]), b0 = lo16(bv[e]), b1 = hi16(bv[e]);
+        oa[e] = pack2(g0 * fmaxf(b0, 0.f), g1 * fmaxf(b1, 0.f));
+        ob[e] = pack2(b0 > 0.f ? g0 * a0 : 0.f, b1 > 0.f ? g1 * a1 : 0.f);
+    }
+    da[i] = oa;
+    db[i] = ob;
+}
+
+__global__ void relu_bwd_bf16_kernel(const u32x4 *__restrict__ dy, const u32x4 *__restrict__ y, u32x4 *__restrict__ dx, long long n8)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 g = dy[i], yv = y[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned keep = ((yv[e] << 16) != 0u && !(yv[e] & 0x8000u) ? 0x0000FFFFu : 0u) |      // y > 0 (a relu output: never negative, +0 or > 0)
+                              ((yv[e] & 0xFFFF0000u) != 0u && !(yv[e] & 0x80000000u) ? 0xFFFF0000u : 0u);
+        o[e] = g[e] & keep;
+    }
+    dx[i] = o;
+}
+
+// ---- ChannelNorm + FiLM, forward: fp32 in, fp32 and/or bf16 out ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *__restrict__ x, const float *__restrict__ film, const int *__restrict__ slot,
+                                                                  float *__restrict__ out32, unsigned short *__restrict__ out16, long long rows, int HW,
+                                                                  int C, float eps, int lpr)
+{
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long row = wave * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const int c4n = C >> 2;
+    const bool live = row < rows;
+    const f32x4 *xr = (const f32x4 *)(x + (live ? row : 0) * C);
+    f32x4 v[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        v[i] = (live && c4 < c4n) ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = group_sum(s, lpr) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i)
+        if (sub + i * lpr < c4n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                ss += d * d;
+            }
+    const float den = sqrtf(group_sum(ss, lpr) / (float)(C - 1) + eps);     // unbiased, modules.py:24
+    if (!live) return;
+    const int b = (int)(row / HW), pix = (int)(row - (long long)b * HW);
+    const int sl = slot ? slot[b] : 0;
+    const f32x4 *fr = (const f32x4 *)(film + ((long long)sl * HW + pix) * 2 * C);
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+            const f32x4 mu = fr[c4], bi = fr[c4n + c4];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn((v[i][e] - mean) / den, mu[e]), bi[e]);
+            if (out32) ((f32x4 *)(out32 + row * C))[c4] = o;
+            if (out16) ((u32x2 *)(out16 + row * C))[c4] = pack4(o);
+        }
+    }
+}
+
+// backward (one FiLM slot per sample: every (slot, pixel) row of dfilm has exactly one writer):
+//   dfilm = (dxf * xn | dxf) as bf16;  dx = dres + (dxn - mean(dxn) - xn * sum(dxn * xn) / (C - 1)) / den, dxn = dxf * mul;  dx16 = bf16(dx)
+__global__ __launch_bounds__(256) void channelnorm_film_bwd_mp_kernel(const float *__restrict__ x, const float *__restrict__ film, const int *__restrict__ slot,
+                                                                      const float *__restrict__ dxf, const float *__restrict__ dres, float *__restrict__ dx,
+                                                                      unsigned short *__restrict__ dx16, unsigned short *__restrict__ dfilm16, long long rows,
+                                                                      int HW, int C, float eps, int lpr)
+{
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long row = wave * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const int c4n = C >> 2;
+    const bool live = row < rows;
+    const long long rr = live ? row : 0;
+    const f32x4 *xr = (const f32x4 *)(x + rr * C);
+    const f32x4 *gr = (const f32x4 *)(dxf + rr * C);
+    const int b = (int)(rr / HW), pix = (int)(rr - (long long)b * HW);
+    const int sl = slot ? slot[b] : 0;
+    const long long frow = ((long long)sl * HW + pix) * 2 * C;
+    const f32x4 *fr = (const f32x4 *)(film + frow);
+    f32x4 v[kMaxV], g[kMaxV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        const bool ok = live && c4 < c4n;
+        v[i] = ok ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = ok ? gr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = group_sum(s, lpr) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i)
+        if (sub + i * lpr < c4n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                ss += d * d;
+            }
+    const float den = sqrtf(group_sum(ss, lpr) / (float)(C - 1) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+            const f32x4 mu = live ? fr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 gm;
+            const f32x4 gx4 = g[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xn = (v[i][e] - mean) / den;
+                const float gx = g[i][e];
+                gm[e] = gx * xn;
+                const float dxn = gx * mu[e];
+                v[i][e] = xn;
+                g[i][e] = dxn;
+                s1 += dxn;
+                s2 += dxn * xn;
+            }
+            if (live) {
+                *(u32x2 *)(dfilm16 + frow + 4 * c4) = pack4(gm);
+                *(u32x2 *)(dfilm16 + frow + C + 4 * c4) = pack4(gx4);
+            }
+        }
+    }
+    s1 = group_sum(s1, lpr) / (float)C;
+    s2 = group_sum(s2, lpr) / (float)(C - 1);
+    if (!live) return;
+    const f32x4 *rres = dres ? (const f32x4 *)(dres + row * C) : nullptr;
+#pragma unroll
+    for (int i = 0; i < kMaxV; ++i) {
+        const int c4 = sub + i * lpr;
+        if (c4 < c4n) {
+            f32x4 o = rres ? rres[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += (g[i][e] - s1 - v[i][e] * s2) / den;
+            ((f32x4 *)(dx + row * C))[c4] = o;
+            if (dx16) ((u32x2 *)(dx16 + row * C))[c4] = pack4(o);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ldm_cast_bf16(const float *x, void *out, long long n, void *stream)
+{
+    LDM_REQUIRE(x && out && n > 0 && n % 4 == 0 && ldm_aligned16(x) && (((size_t)out) & 7) == 0, "ldm_cast_bf16: n=%lld must be a multiple of 4, pointers aligned", n);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (u32x2 *)out, n / 4);
+    LDM_CHECK_LAUNCH("ldm_cast_bf16");
+    return LDM_OK;
+}
+
+extern "C" int ldm_uncast_bf16(const void *x, float *out, long long n, void *stream)
+{
+    LDM_REQUIRE(x && out && n > 0 && n % 4 == 0 && ldm_aligned16(out) && (((size_t)x) & 7) == 0, "ldm_uncast_bf16: n=%lld must be a multiple of 4, pointers aligned", n);
+    hipLaunchKernelGGL(uncast_bf16_kernel, dim3(blocks_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x2 *)x, (f32x4 *)out, n / 4);
+    LDM_CHECK_LAUNCH("ldm_uncast_bf16");
+    return LDM_OK;
+}
+
+extern "C" int ldm_transpose_cast_bf16(const float *x, void *out, long long R, int C, void *stream)
+{
+    LDM_REQUIRE(x && out && R > 0 && C > 0 && (R + 63) / 64 <= 65535, "ldm_transpose_cast_bf16: bad shape R=%lld C=%d", R, C);
+    hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3((C + 63) / 64, (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short *)out, R, C);
+    LDM_CHECK_LAUNCH("ldm_transpose_cast_bf16");
+    return LDM_OK;
+}
+
+#define LDM_BF16_ELEMENTWISE(name, kern, ...)                                                                                                   \
+    LDM_REQUIRE(n > 0 && n % 8 == 0, name ": n=%lld must be a positive multiple of 8", n);                                                      \
+    hipLaunchKernelGGL(kern, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                                     \
+    LDM_CHECK_LAUNCH(name);                                                                                                                     \
+    return LDM_OK;
+
+extern "C" int ldm_gate_fwd_bf16(const void *a, const void *b, void *out, long long n, void *stream)
+{
+    LDM_REQUIRE(a && b && out && ldm_aligned16(a) && ldm_aligned16(b) && ldm_aligned16(out), "ldm_gate_fwd_bf16: null / unaligned pointer");
+    LDM_BF16_ELEMENTWISE("ldm_gate_fwd_bf16", gate_fwd_bf16_kernel, (const u32x4 *)a, (const u32x4 *)b, (u32x4 *)out, n / 8)
+}
+
+extern "C" int ldm_gate_bwd_bf16(const void *dh, const void *a, const void *b, void *da, void *db, long long n, void *stream)
+{
+    LDM_REQUIRE(dh && a && b && da && db && ldm_aligned16(dh) && ldm_aligned16(a) && ldm_aligned16(b) && ldm_aligned16(da) && ldm_aligned16(db),
+                "ldm_gate_bwd_bf16: null / unaligned pointer");
+    LDM_BF16_ELEMENTWISE("ldm_gate_bwd_bf16", gate_bwd_bf16_kernel, (const u32x4 *)dh, (const u32x4 *)a, (const u32x4 *)b, (u32x4 *)da, (u32x4 *)db, n / 8)
+}
+
+extern "C" int ldm_relu_bwd_bf16(const void *dy, const void *y, void *dx, long long n, void *stream)
+{
+    LDM_REQUIRE(dy && y && dx && ldm_aligned16(dy) && ldm_aligned16(y) && ldm_aligned16(dx), "ldm_relu_bwd_bf16: null / unaligned pointer");
+    LDM_BF16_ELEMENTWISE("ldm_relu_bwd_bf16", relu_bwd_bf16_kernel, (const u32x4 *)dy, (const u32x4 *)y, (u32x4 *)dx, n / 8)
+}
+
+extern "C" int ldm_channelnorm_film_bf16(const float *x, const float *film, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
+                                         void *stream)
+{
+    LDM_REQUIRE(x && film && (out_f32 || out_bf16), "ldm_channelnorm_film_bf16: null pointer");
+    LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_bf16: bad shape B=%d HW=%d C=%d", B, HW, C);
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(film) && ldm_aligned16(out_f32) && (((size_t)out_bf16) & 7) == 0, "ldm_channelnorm_film_bf16: unaligned pointer");
+    const int lpr = pow2_lanes(C / 4);
+    const long long rows = (long long)B * HW;
+    const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL(channelnorm_film_mp_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, out_f32,
+                       (unsigned short *)out_bf16, rows, HW, C, eps, lpr);
+    LDM_CHECK_LAUNCH("ldm_channelnorm_film_bf16");
+    return LDM_OK;
+}
+
+extern "C" int ldm_channelnorm_film_bwd_bf16(const float *x, const float *film, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
+                                             void *dfilm_bf16, int B, int HW, int C, float eps, void *stream)
+{
+    LDM_REQUIRE(x && film && dxf && dx && dfilm_bf16, "ldm_channelnorm_film_bwd_bf16: null pointer");
+    LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_bwd_bf16: bad shape");
+    const int lpr = pow2_lanes(C / 4);
+    const long long rows = (long long)B * HW;
+    const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL(channelnorm_film_bwd_mp_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, dxf, dres, dx,
+                       (unsigned short *)dx_bf16, (unsigned short *)dfilm_bf16, rows, HW, C, eps, lpr);
+    LDM_CHECK_LAUNCH("ldm_channelnorm_film_bwd_bf16");
+    return LDM_OK;
+}

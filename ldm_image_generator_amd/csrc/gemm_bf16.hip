@@ -1,0 +1,228 @@
+// bf16-operand GEMMs of the training step (BASELINE cfg 5: "bf16 ... fwd+bwd HIP kernels"; the reference itself trains under
+// reduced-precision autocast, train_ldm.py:68,80).  Operands are rounded ONCE to bf16 by their producers, products are
+// accumulated in fp32 on v_mfma_f32_32x32x16_bf16, master weights / gradients / AdamW stay fp32.
+//
+//   ldm_gemm_bf16     out = act(A . W^T + bias) (+ addend)     -- the persistent LDS-DMA stream kernel of gemm_stream.hip with ET = 1
+//   ldm_gemm_tn_bf16  out[s] = A_s^T . B_s  (weight gradients)  -- this file: operands as they lie in memory, MFMA fragments by
+//                                                                  ds_read_b64_tr_b16 (the LDS transposing read of gfx950)
+#include "gemm_common.h"
+
+using namespace ldmgemm;
+
+int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st);
+
+extern "C" int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream)
+{
+    LDM_REQUIRE(d != nullptr && d->a && d->out, "ldm_gemm_bf16: null descriptor / operand");
+    LDM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->N % 64 == 0 && d->K % 64 == 0, "ldm_gemm_bf16: M=%d, N=%d and K=%d must be positive multiples of (1, 64, 64)",
+                d->M, d->N, d->K);
+    LDM_REQUIRE(d->a_mode == LDM_A_ROWS && d->o_mode == LDM_O_ROWS && d->act != LDM_ACT_GATE && !d->w_table,
+                "ldm_gemm_bf16: rows in / rows out, no gate, no pointer table");
+    LDM_REQUIRE(d->nseg >= 1 && d->nseg <= LDM_MAX_SEG && (d->seg_mode == LDM_SEG_N || d->seg_mode == LDM_SEG_K), "ldm_gemm_bf16: nseg=%d seg_mode=%d", d->nseg,
+                d->seg_mode);
+    LDM_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && ldm_aligned16(d->a), "ldm_gemm_bf16: rows of A and W must be 16-byte addressable (lda, ldw multiples of 8)");
+    const int groups = d->groups > 0 ? d->groups : 1;
+    LDM_REQUIRE(d->a_gstride % 8 == 0 && d->w_gstride % 8 == 0, "ldm_gemm_bf16: group strides must be multiples of 8 elements");
+    const int seg_total = d->seg_mode == LDM_SEG_N ? d->N : d->K;
+    const int seg_len = d->nseg == 1 ? seg_total : d->seg_len;
+    LDM_REQUIRE(seg_len > 0 && seg_len % 64 == 0 && (long long)seg_len * d->nseg == seg_total, "ldm_gemm_bf16: segments (%d x %d) do not cover %d", d->nseg,
+                seg_len, seg_total);
+    for (int s = 0; s < d->nseg; ++s) LDM_REQUIRE(d->w[s] && ldm_aligned16(d->w[s]), "ldm_gemm_bf16: weight segment %d null/unaligned", s);
+    LDM_REQUIRE(!(out_bf16 && d->addend), "ldm_gemm_bf16: an addend needs the fp32 output");
+    if (out_bf16)
+        LDM_REQUIRE((((size_t)d->out) & 7) == 0 && d->ldo % 4 == 0 && d->o_gstride % 4 == 0, "ldm_gemm_bf16: bf16 output must be 8-byte addressable");
+    GemmP p{};
+    p.a = d->a; p.lda = d->lda / 2; p.M = d->M; p.N = d->N; p.K = d->K / 2;          // K axis in 4-byte units from here on
+    p.cpt = 1;
+    p.nseg = d->nseg; p.seg_mode = d->seg_mode;
+    p.seg_len = d->seg_mode == LDM_SEG_K ? seg_len / 2 : seg_len;
+    for (int s = 0; s < LDM_MAX_SEG; ++s) {
+        p.w[s] = s < d->nseg ? d->w[s] : nullptr;
+        p.bias[s] = s < d->nseg ? d->bias[s] : nullptr;
+    }
+    p.ldw = d->ldw / 2; p.act = d->act; p.slope = d->slope;
+    p.addend = d->addend; p.ldadd = d->ldadd; p.out = d->out; p.ldo = d->ldo;
+    p.o_mode = LDM_O_ROWS;
+    p.a_gstride = d->a_gstride / 2; p.w_gstride = d->w_gstride / 2; p.o_gstride = d->o_gstride; p.b_gstride = d->b_gstride;
+    p.wide_ok = out_bf16 ? 1
+                         : (ldm_aligned16(d->out) && d->ldo % 4 == 0 && d->o_gstride % 4 == 0 && (!d->addend || (ldm_aligned16(d->addend) && d->ldadd % 4 == 0)));
+    hipStream_t st = (hipStream_t)stream;
+    const double mn = (double)d->M * d->N * groups;
+    void *rec = ldm_prof_begin(LDM_PROF_GEMM_BF16, 2.0 * mn * d->K, st,
+                               2.0 * ((double)d->M * d->K * (d->a_gstride || groups == 1 ? groups : 1) + (double)d->N * d->K * groups) +
+                                   mn * (out_bf16 ? 2.0 : 4.0) + (d->addend ? mn * 4.0 : 0.0));
+    const int ok = ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st);
+    ldm_prof_end(rec, st);
+    LDM_REQUIRE(ok, "ldm_gemm_bf16: no kernel instance for this shape (N=%d, seg_len=%d)", d->N, seg_len);
+    LDM_CHECK_LAUNCH("ldm_gemm_bf16");
+    return LDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// TN: out[s][n][k] = sum over rows m of split s of A[m][n] * B[m][k]   (dW = dY^T X, autograd of every 1x1 conv / Linear)
+//
+// Stage = [BR = 64 rows][128 columns] bf16 of each operand (256-byte LDS rows, 16 chunks of 16 B), filled by LDS-DMA as the
+// rows lie in memory.  The MFMA wants, per lane, 8 consecutive m of ONE column: two ds_read_b64_tr_b16 (each hands a lane
+// 4 rows of its column out of a 4 x 16 block read by 16 lanes).  Chunk swizzle on the DMA source side and on the reads:
+// physical chunk = logical ^ (((row & 3) << 2) | ((row >> 2) & 3)), the conflict-free image for transposed 32x32x16 operand reads.
+// 128 x 128 output tile per workgroup, 4 waves of 64 x 64; split over M on the grid, partial planes summed by the caller.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
+
+struct TnP16 {
+    const unsigned short *a, *b;
+    float *out, *colsum;
+    long long lda, ldb;
+    int M, N, K, ms, splits, ntn, ntk;
+};
+
+constexpr int TBT = 128;             // output tile edge
+constexpr int TBR = 64;              // contraction rows per stage
+constexpr int TSTAGE = 2 * TBR * TBT;   // bf16 elements per stage (A then B)
+
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int T = p.ntn * p.ntk;
+    int tile, split;
+    if (p.splits % 8 == 0) {               // tiles of one split on one XCD (they read the same operand rows): see gemm_tn.hip
+        const int b = (int)blockIdx.x, blk = b / (8 * T), in = b - blk * 8 * T;
+        split = blk * 8 + (in & 7);
+        tile = in >> 3;
+    } else {
+        tile = (int)blockIdx.x % T;
+        split = (int)blockIdx.x / T;
+    }
+    const int n0 = (tile / p.ntk) * TBT, k0 = (tile % p.ntk) * TBT;
+    const long long row0 = (long long)split * p.ms;
+    const int nsteps = p.ms / TBR;
+
+    // DMA: one instruction = 64 lanes x 16 B = 4 rows of one operand tile; a wave moves rows 4 (4 i + wave) .. + 3, i < 4
+    const int drow = lane >> 4, dchunk = lane & 15;
+    auto issue = [&](int step) {
+        unsigned short *As = lds16 + (step & 1) * TSTAGE, *Bs = As + TBR * TBT;
+        const long long mbase = row0 + (long long)step * TBR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * (4 * i + wave) + drow;
+            const int csrc = (dchunk ^ tn_swz(row)) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.a + (mbase + row) * p.lda + n0 + csrc), (lptr_t)(As + (4 * i + wave) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.b + (mbase + row) * p.ldb + k0 + csrc), (lptr_t)(Bs + (4 * i + wave) * 512), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // transposed fragment read.  Lane l: group g = l >> 4 (0..3), q = (l >> 2) & 3, pp = l & 3.  The operand lane (r = l & 31,
+    // hh = l >> 5) needs rows m = mb + 8 hh + {0..7} of column c0 + r: group g covers columns c0 + 16 (g & 1) .. + 15 and rows
+    // mb + 8 (g >> 1) + {0..3} (first read) / + {4..7} (second read).  The address a lane SUPPLIES is row q of that block, columns 4 pp .. 4 pp + 3.
+    const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto frag = [&](const unsigned short *base, int mb, int c0) -> s16x8 {
+        const int col = c0 + 16 * (grp & 1) + 4 * pp;
+        const int rowa = mb + 8 * (grp >> 1) + q, rowb = rowa + 4;
+        const unsigned short *pa = base + rowa * TBT + (((col >> 3) ^ tn_swz(rowa)) << 3) + (col & 7);
+        const unsigned short *pb = base + rowb * TBT + (((col >> 3) ^ tn_swz(rowb)) << 3) + (col & 7);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pa);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pb);
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    const bool want_cs = p.colsum != nullptr && k0 == 0 && wn == 0;      // one workgroup column and one wave column own each A column
+    float cs[2] = {0.f, 0.f};            // column sums of A: this lane's column of each of its two A tiles, its 8 rows per 16-row slice
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) issue(step + 1);
+        const unsigned short *As = lds16 + (step & 1) * TSTAGE, *Bs = As + TBR * TBT;
+#pragma unroll
+        for (int s = 0; s < TBR / 16; ++s) {
+            s16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = frag(As, 16 * s, wm * 64 + 32 * i);
+                b[i] = frag(Bs, 16 * s, wn * 64 + 32 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (want_cs) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[i] += bf16_lo((unsigned)(unsigned short)a[i][e]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const int r = lane & 31, h = lane >> 5;
+    if (want_cs) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float s_ = cs[i] + __shfl_xor(cs[i], 32);
+            if (h == 0) p.colsum[(long long)split * p.N + n0 + wm * 64 + 32 * i + r] = s_;
+        }
+    }
+    // C/D map: column = lane & 31 (k index), row = (e & 3) + 8 (e >> 2) + 4 h (n index)
+    float *obase = p.out + (long long)split * p.N * p.K + (long long)(n0 + wm * 64) * p.K + k0 + wn * 64 + r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) obase[(long long)row * p.K + 32 * j] = acc[i][j][e];
+        }
+}
+
+}  // namespace
+
+extern "C" int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, long long ldb, float *out, float *colsum_a, int M, int N, int K, int splits,
+                                void *stream)
+{
+    LDM_REQUIRE(a && b && out, "ldm_gemm_tn_bf16: null pointer");
+    LDM_REQUIRE(M > 0 && N > 0 && K > 0 && N % TBT == 0 && K % TBT == 0, "ldm_gemm_tn_bf16: N=%d and K=%d must be multiples of 128", N, K);
+    LDM_REQUIRE(splits >= 1 && M % splits == 0 && (M / splits) % TBR == 0, "ldm_gemm_tn_bf16: M=%d must split into %d runs of a multiple of 64 rows", M, splits);
+    LDM_REQUIRE(lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldm_aligned16(a) && ldm_aligned16(b),
+                "ldm_gemm_tn_bf16: operands must be 16-byte addressable (lda=%lld ldb=%lld)", lda, ldb);
+    TnP16 p{};
+    p.a = (const unsigned short *)a; p.b = (const unsigned short *)b; p.out = out; p.colsum = colsum_a; p.lda = lda; p.ldb = ldb;
+    p.M = M; p.N = N; p.K = K; p.ms = M / splits; p.splits = splits; p.ntn = N / TBT; p.ntk = K / TBT;
+    const long long blocks = (long long)p.ntn * p.ntk * splits;
+    LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_gemm_tn_bf16: grid too large");
+    constexpr size_t smem = 2ull * TSTAGE * sizeof(unsigned short);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    void *rec = ldm_prof_begin(LDM_PROF_TN_BF16, 2.0 * M * (double)N * K, (hipStream_t)stream, 2.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
+    ldm_prof_end(rec, (hipStream_t)stream);
+    LDM_CHECK_LAUNCH("ldm_gemm_tn_bf16");
+    return LDM_OK;
+}

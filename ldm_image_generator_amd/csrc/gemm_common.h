@@ -289,7 +289,16 @@ __device__ __forceinline__ void gemm_prefetch_addend_wide(const GemmP &p, float 
         }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE>
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of two bf16, round to nearest even, NaN stays NaN (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+template <int WM, int WN, int TM, int TN, bool GATE, bool OBF = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int n0, int g, int wm, int wn,
                                                    const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre,
                                                    const WideLane<TN> &wl, float *scratch /* stage base + wave * 256 */)
@@ -302,7 +311,9 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmP &p, f32x16 (&acc)
     const int row0 = m0 + wm * TM * 32 + wl.rsub;
     const bool full = m0 + WM * TM * 32 <= p.M;
     const int ldo_ = (int)p.ldo;
-    float *obase = p.out + (long long)row0 * p.ldo + g * p.o_gstride + n0 + wn * TN * 32 + 4 * wl.cc;
+    const long long oelem = (long long)row0 * p.ldo + g * p.o_gstride + n0 + wn * TN * 32 + 4 * wl.cc;     // same element offset for both output types
+    float *obase = p.out + oelem;
+    unsigned short *obase16 = (unsigned short *)p.out + oelem;
     float *wr = scratch + wl.wr_off;
     const float *rd = scratch + wl.rd_off;
 #pragma unroll
@@ -335,7 +346,14 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmP &p, f32x16 (&acc)
                 for (int cix = 0; cix < 4; ++cix) v[cix] += pre[im][(4 * k + cix) >> 4][(4 * k + cix) & 15];
             }
             const int roff = im * 32 + k * RPI;
-            if (full || row0 + roff < p.M) *(f32x4 *)(obase + roff * ldo_) = v;
+            if (full || row0 + roff < p.M) {
+                if constexpr (OBF) {
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    *(u32x2_t *)(obase16 + roff * ldo_) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                } else {
+                    *(f32x4 *)(obase + roff * ldo_) = v;
+                }
+            }
         }
     }
 }

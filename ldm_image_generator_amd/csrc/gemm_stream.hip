@@ -83,9 +83,14 @@ __device__ __forceinline__ void mfma6(const Split3 &a, const Split3 &b, f32x16 &
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false>
+// ET = 1: both operands are bf16 (rows of 128 B = 64 k), one v_mfma_f32_32x32x16_bf16 per fragment pair; the loader, the LDS
+// ring and the swizzle are unchanged because they only ever move 16-byte chunks of 128-byte rows -- the host passes K, lda,
+// ldw and the group strides in units of 4 bytes (two bf16).  OBF: the (wide) epilogue rounds the result to bf16 (RNE).
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
+    static_assert(ET == 0 || SPLIT == 0, "bf16 operands: no split consumer");
+    static_assert(!OBF || WIDE, "bf16 output goes through the wide epilogue");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr int A_F4 = BM / 32, B_F4 = NB / 32;
@@ -243,6 +248,19 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
             for (int i = 0; i < TN; ++i) bf[q][i] = *(const f32x4 *)(Bs + swz(q * BN + (wn * TN + i) * 32 + r, c));
     };
     auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[NACC][TN]) {
+        if constexpr (ET == 1) {
+            // a 16-byte chunk = 8 consecutive k of the lane's row: exactly the A / B fragment of the 32x32x16 instruction
+            // (lane half h holds k = 8 h .. 8 h + 7 of the 16-k slice 2 j + h -> slice j)
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[q][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[q][jj]),
+                                                                                acc[q][i][jj], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -396,21 +414,21 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
             mma(fa1, fb1);
         }
         if constexpr (WIDE)      // scratch: this wave's slices of the stage the tile's last step has just released
-            gemm_epilogue_wide<WM, WN, TM, TN, GATE>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
+            gemm_epilogue_wide<WM, WN, TM, TN, GATE, OBF>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
         else
             gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
         ++s;
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false>
 int launch_stream(const GemmP &p, int groups, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
     static int slots = 0;
-    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE>;
+    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE, ET, OBF>;
     if (slots == 0) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int dev = 0, cus = 256;
@@ -483,4 +501,26 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
     if (unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS>(p, groups, st);
     if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_ROWS>(p, groups, st);
     return launch_stream_w<4, 1, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+}
+
+
+// bf16 operands (ldm_gemm_bf16): plain rows in, rows out (fp32 or bf16); p is already in 4-byte units along K.
+int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st)
+{
+    const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
+    const bool big = unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512;
+    if (out_bf16) {
+        if (!p.wide_ok) return 0;
+        if (big) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, 0, true, 1, true>(p, groups, st);
+        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, true, 1, true>(p, groups, st);
+        return 0;
+    }
+    if (p.wide_ok && g_wide) {
+        if (big) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, 0, true, 1, false>(p, groups, st);
+        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, true, 1, false>(p, groups, st);
+        return 0;
+    }
+    if (big) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, 0, false, 1, false>(p, groups, st);
+    if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, false, 1, false>(p, groups, st);
+    return 0;
 }

@@ -330,3 +330,88 @@ def im2col3x3_t(x, out, B, H, W, C):
 def window_attention_bwd(qkv, in_proj_bias, xf, dctx, dqkv, dbias_pad, B, H, W, C, ws, shift):
     _call("ldm_window_attention_bwd_f32", _dev(qkv, "qkv"), _dev(in_proj_bias, "bias"), _opt(xf, "xf"), _dev(dctx, "dctx"),
           _dev(dqkv, "dqkv"), _dev(dbias_pad, "dbias_pad"), B, H, W, C, ws, shift)
+
+
+# ---- bf16 training step (include/ldm_hip.h, "bf16 training step") --------------------------------------
+BF16 = torch.bfloat16
+
+
+def gemm_bf16(a, M, N, K, weights, out, *, lda=None, ldo=None, biases=None, ldw=None, seg_mode=SEG_N, act=ACT_NONE, slope=0.0,
+              addend=None, ldadd=None):
+    """out = act(A . W^T + bias) (+ addend) with bf16 A and W (fp32 accumulate); ``out`` is fp32 or bf16 by its dtype."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.a = _dev(a, "a", BF16)
+    d.lda = K if lda is None else lda
+    d.M, d.N, d.K = M, N, K
+    d.a_mode = A_ROWS
+    nseg = len(weights)
+    d.nseg, d.seg_mode = nseg, seg_mode
+    d.seg_len = (N if seg_mode == SEG_N else K) // nseg
+    for s in range(nseg):
+        d.w[s] = _dev(weights[s], "weight", BF16)
+        if biases is not None and biases[s] is not None:
+            d.bias[s] = _dev(biases[s], "bias")
+    d.ldw = (K if seg_mode == SEG_N else K // nseg) if ldw is None else ldw
+    d.act, d.slope = act, slope
+    d.addend = _opt(addend, "addend")
+    d.ldadd = N if ldadd is None else ldadd
+    out_bf16 = out.dtype == BF16
+    d.out = _dev(out, "out", BF16 if out_bf16 else torch.float32)
+    d.ldo = N if ldo is None else ldo
+    d.o_mode = O_ROWS
+    d.groups = 1
+    _lib.check(lib.ldm_gemm_bf16(ctypes.byref(d), int(out_bf16), _stream()), "ldm_gemm_bf16")
+    return out
+
+
+def gemm_tn_bf16(a, b, out, M, N, K, splits=1, lda=None, ldb=None, colsum=None):
+    """out[s] [N, K] fp32 = sum over the rows of split s of a[m, :N]^T b[m, :K], bf16 operands as they lie in memory."""
+    _call("ldm_gemm_tn_bf16", _dev(a, "a", BF16), N if lda is None else lda, _dev(b, "b", BF16), K if ldb is None else ldb, _dev(out, "out"),
+          _opt(colsum, "colsum"), M, N, K, splits)
+    return out
+
+
+def cast_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _call("ldm_cast_bf16", _dev(x, "x"), _dev(out, "out", BF16), x.numel())
+    return out
+
+
+def transpose_cast_bf16(x, out=None):
+    r, c = x.shape
+    if out is None:
+        out = torch.empty(c, r, device=x.device, dtype=BF16)
+    _call("ldm_transpose_cast_bf16", _dev(x, "x"), _dev(out, "out", BF16), r, c)
+    return out
+
+
+def gate_fwd_bf16(a, b, out):
+    _call("ldm_gate_fwd_bf16", _dev(a, "a", BF16), _dev(b, "b", BF16), _dev(out, "out", BF16), a.numel())
+    return out
+
+
+def gate_bwd_bf16(dh, a, b, da, db):
+    _call("ldm_gate_bwd_bf16", _dev(dh, "dh", BF16), _dev(a, "a", BF16), _dev(b, "b", BF16), _dev(da, "da", BF16), _dev(db, "db", BF16), a.numel())
+
+
+def relu_bwd_bf16(dy, y, dx):
+    _call("ldm_relu_bwd_bf16", _dev(dy, "dy", BF16), _dev(y, "y", BF16), _dev(dx, "dx", BF16), y.numel())
+    return dx
+
+
+def channelnorm_film_bf16(x, film, slot, out_f32, out_bf16, B, HW, C, eps=1e-4):
+    _call("ldm_channelnorm_film_bf16", _dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32), _opt(out_f32, "out_f32"),
+          _opt(out_bf16, "out_bf16", BF16), B, HW, C, eps)
+
+
+def channelnorm_film_bwd_bf16(x, film, slot, dxf, dres, dx, dx_bf16, dfilm_bf16, B, HW, C, eps=1e-4):
+    _call("ldm_channelnorm_film_bwd_bf16", _dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32), _dev(dxf, "dxf"), _opt(dres, "dres"),
+          _dev(dx, "dx"), _opt(dx_bf16, "dx_bf16", BF16), _dev(dfilm_bf16, "dfilm_bf16", BF16), B, HW, C, eps)
+    return dx
+
+
+def uncast_bf16(x, out):
+    _call("ldm_uncast_bf16", _dev(x, "x", BF16), _dev(out, "out"), x.numel())
+    return out

@@ -308,6 +308,224 @@ def encodings_backward(enc, codes, hid, dfilm, grads):
 
 
 # ------------------------------------------------------------------------------------------------------
+# bf16 operands (BASELINE cfg 5 names bf16; the reference trains under reduced-precision autocast, train_ldm.py:68,80)
+#
+# Every 1x1-conv / Linear GEMM of the step -- forward, data gradient, weight gradient -- takes bf16 operands that their
+# producers rounded ONCE (round-to-nearest-even) and accumulates in fp32 (v_mfma_f32_32x32x16_bf16).  What stays fp32: the
+# residual stream and its gradient (each with a bf16 shadow copy for the GEMMs that read it), FiLM rows, the grouped 3x3
+# conv (its three kernels), window attention, stem / head / ch_convs, every parameter gradient and AdamW's master weights.
+# ------------------------------------------------------------------------------------------------------
+PRECISIONS = ("f32", "bf16")
+BF16 = torch.bfloat16
+
+
+def set_precision(net, precision):
+    """Operand precision of the training step of ``net`` (a UNet): "f32" (exact-fp32 MFMA, default) or "bf16"."""
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %r" % (PRECISIONS,))
+    net.train_precision = precision
+
+
+class _Weight16:
+    """bf16 copies of a parameter viewed as [N, K]: as it lies (forward) and transposed [K, N] (data gradients); one cast per
+    parameter version (= per optimizer step)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, p, transposed=False):
+        key = (p.data_ptr(), p._version)
+        hit = self.cache.get(id(p))
+        if hit is None or hit[0] != key:
+            hit = [key, None, None]
+            self.cache[id(p)] = hit
+        if hit[1 + int(transposed)] is None:
+            w = _w2d(p)
+            hit[1 + int(transposed)] = ops.transpose_cast_bf16(w.contiguous()) if transposed else ops.cast_bf16(w.contiguous())
+        return hit[1 + int(transposed)]
+
+
+W16 = _Weight16()
+
+
+def _e16(*shape, dev):
+    return torch.empty(*shape, device=dev, dtype=BF16)
+
+
+def _uncast(x16):
+    """bf16 -> fp32 copy (narrow test layers only: the fp32 weight-gradient fallback)."""
+    out = torch.empty(x16.shape, device=x16.device, dtype=torch.float32)
+    ops.uncast_bf16(x16, out)
+    return out
+
+
+def grad_weight_rows16(dy16, x16, m_red, want_colsum=True):
+    """(dW [N, K] fp32, column sums of dy [N] fp32 or None) for bf16 row-major dy [M, N], x [M, K]: the TN bf16 kernel with the
+    operands as they lie in memory; layers it does not cover (N or K not a multiple of 128, M not a multiple of 64: tiny test
+    nets) are up-cast and take the fp32 route."""
+    n_out, k_out = dy16.shape[1], x16.shape[1]
+    dev = dy16.device
+    if n_out % 128 or k_out % 128 or m_red % 64:
+        dy_r = _Rows(_uncast(dy16))
+        dw = grad_weight_rows(dy_r, _Rows(_uncast(x16)), m_red)
+        return dw, (dy_r.colsum() if want_colsum else None)
+    tiles = (n_out // 128) * (k_out // 128)
+    s = 1
+    while tiles * s < 512 and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:
+        s *= 2
+    out = torch.empty(n_out, k_out, device=dev, dtype=torch.float32)
+    cs = torch.empty(s, n_out, device=dev, dtype=torch.float32) if want_colsum else None
+    if s == 1:
+        ops.gemm_tn_bf16(dy16, x16, out, m_red, n_out, k_out, 1, colsum=cs)
+        return out, (cs[0] if want_colsum else None)
+    parts = torch.empty(s, n_out, k_out, device=dev, dtype=torch.float32)
+    ops.gemm_tn_bf16(dy16, x16, parts, m_red, n_out, k_out, s, colsum=cs)
+    ops.reduce_partials(parts, s, n_out * k_out, out)
+    if want_colsum:
+        cs = ops.reduce_partials(cs, s, n_out, torch.empty(n_out, device=dev, dtype=torch.float32))
+    return out, cs
+
+
+def encodings_forward16(enc, codes16):
+    m, c = codes16.shape[0], enc.channels
+    dev = codes16.device
+    hid = _e16(m, 4 * c, dev=dev)
+    ops.gemm_bf16(codes16, m, 4 * c, 2 * c, [W16.get(enc.proj1.weight)], hid, biases=[enc.proj1.bias.detach()], act=ops.ACT_RELU)
+    film = torch.empty(m, 2 * c, device=dev, dtype=torch.float32)
+    ops.gemm_bf16(hid, m, 2 * c, 4 * c, [W16.get(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
+    return hid, film
+
+
+def encodings_backward16(enc, codes16, hid16, dfilm16, grads):
+    m, c = codes16.shape[0], enc.channels
+    dw2, db2 = grad_weight_rows16(dfilm16, hid16, m)
+    grads.add(enc.proj2.weight, dw2)
+    grads.add(enc.proj2.bias, db2)
+    dh = _e16(m, 4 * c, dev=codes16.device)
+    ops.gemm_bf16(dfilm16, m, 4 * c, 2 * c, [W16.get(enc.proj2.weight, True)], dh)
+    ops.relu_bwd_bf16(dh, hid16, dh)
+    dw1, db1 = grad_weight_rows16(dh, codes16, m)
+    grads.add(enc.proj1.weight, dw1)
+    grads.add(enc.proj1.bias, db1)
+
+
+def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
+    """block_forward with bf16 GEMM operands; ``rows`` (the residual stream) and the result stay fp32."""
+    b, h, w = shape
+    m, c = rows.shape
+    dev = rows.device
+    xf = torch.empty_like(rows)                         # fp32: grouped conv, attention's float "mask"
+    xf16 = _e16(m, c, dev=dev)
+    ops.channelnorm_film_bf16(rows, film, ctx.slot, xf, xf16, b, h * w, c, blk.norm.eps)
+    y = torch.empty_like(rows)
+    ops.gemm(xf, m, 32, 288, [blk._conv_weight()], y, lda=c, ldw=288, biases=[blk.conv.bias.detach()], addend=rows, ldadd=c,
+             ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=32, groups=c // 32, a_gstride=32, w_gstride=32 * 288,
+             o_gstride=32, b_gstride=32)
+    sv = dict(blk=blk, x=rows, xf=xf, xf16=xf16, film=film, codes=codes16, enc_hidden=enc_hidden16, picks=picks, shape=shape)
+    if blk.attention_flag:
+        att = blk.self_attention.attention
+        qkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
+        ops.gemm_bf16(xf16, m, 3 * c, c, [W16.get(att.in_proj_weight)], qkv, biases=[att.in_proj_bias.detach()])
+        actx = torch.empty(m, c, device=dev, dtype=torch.float32)
+        ops.window_attention(qkv, att.in_proj_bias.detach(), xf, actx, b, h, w, c, blk.self_attention.window_size,
+                             blk.self_attention.shift)
+        actx16 = ops.cast_bf16(actx)
+        ops.gemm_bf16(actx16, m, c, c, [W16.get(att.out_proj.weight)], y, biases=[att.out_proj.bias.detach()], addend=y)
+        sv.update(qkv=qkv, actx16=actx16)
+    regs = [blk.ffn.general] + [blk.ffn.experts[i] for i in picks]
+    f = regs[0].a.weight.shape[0]
+    a_pre, b_pre, hid = _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev)
+    ops.gemm_bf16(xf16, m, 3 * f, c, [W16.get(r.a.weight) for r in regs], a_pre, biases=[r.a.bias.detach() for r in regs])
+    ops.gemm_bf16(xf16, m, 3 * f, c, [W16.get(r.b.weight) for r in regs], b_pre, biases=[r.b.bias.detach() for r in regs])
+    ops.gate_fwd_bf16(a_pre, b_pre, hid)
+    ops.gemm_bf16(hid, m, c, 3 * f, [W16.get(r.c.weight) for r in regs], y, biases=[r.c.bias.detach() for r in regs],
+                  seg_mode=ops.SEG_K, addend=y)
+    sv.update(regs=regs, a_pre=a_pre, b_pre=b_pre, hid=hid)
+    return y, sv
+
+
+def block_backward16(sv, dy, dy16, ctx, grads):
+    """-> (dx fp32, dx as bf16).  dy16 is the bf16 shadow of dy (the GEMM operand)."""
+    blk, x, xf, xf16, shape = sv["blk"], sv["x"], sv["xf"], sv["xf16"], sv["shape"]
+    b, h, w = shape
+    m, c = x.shape
+    dev = x.device
+    regs = sv["regs"]
+    f = regs[0].a.weight.shape[0]
+    # ---- RandomMoE ------------------------------------------------------------------------------------
+    dwc, bias_dy = grad_weight_rows16(dy16, sv["hid"], m)            # [C, 3F], [C]
+    dhid = _e16(m, 3 * f, dev=dev)
+    ops.gemm_bf16(dy16, m, 3 * f, c, [W16.get(r.c.weight, True) for r in regs], dhid)
+    da, db = _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev)
+    ops.gate_bwd_bf16(dhid, sv["a_pre"], sv["b_pre"], da, db)
+    dxf = torch.empty(m, c, device=dev, dtype=torch.float32)
+    ops.gemm_bf16(da, m, c, 3 * f, [W16.get(r.a.weight, True) for r in regs], dxf, seg_mode=ops.SEG_K)
+    ops.gemm_bf16(db, m, c, 3 * f, [W16.get(r.b.weight, True) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)
+    dwa, dba = grad_weight_rows16(da, xf16, m)                        # [3F, C]
+    dwb, dbb = grad_weight_rows16(db, xf16, m)
+    for e, r in enumerate(regs):
+        grads.add(r.c.weight, dwc[:, e * f:(e + 1) * f])
+        grads.add(r.c.bias, bias_dy.clone())
+        grads.add(r.a.weight, dwa[e * f:(e + 1) * f])
+        grads.add(r.b.weight, dwb[e * f:(e + 1) * f])
+        grads.add(r.a.bias, dba[e * f:(e + 1) * f])
+        grads.add(r.b.bias, dbb[e * f:(e + 1) * f])
+    # ---- window attention ---------------------------------------------------------------------------
+    if blk.attention_flag:
+        att = blk.self_attention.attention
+        dctx = torch.empty(m, c, device=dev, dtype=torch.float32)
+        ops.gemm_bf16(dy16, m, c, c, [W16.get(att.out_proj.weight, True)], dctx)
+        dwo, _ = grad_weight_rows16(dy16, sv["actx16"], m, want_colsum=False)
+        grads.add(att.out_proj.weight, dwo)
+        grads.add(att.out_proj.bias, bias_dy.clone())
+        dqkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
+        dpad = torch.empty(3 * c, device=dev, dtype=torch.float32)
+        ops.window_attention_bwd(sv["qkv"], att.in_proj_bias.detach(), xf, dctx, dqkv, dpad, b, h, w, c,
+                                 blk.self_attention.window_size, blk.self_attention.shift)
+        dqkv16 = ops.cast_bf16(dqkv)
+        ops.gemm_bf16(dqkv16, m, c, 3 * c, [W16.get(att.in_proj_weight, True)], dxf, addend=dxf)
+        dwi, dbi = grad_weight_rows16(dqkv16, xf16, m)
+        grads.add(att.in_proj_weight, dwi)
+        grads.add(att.in_proj_bias, ops.add_(dbi.clone(), dpad))
+    # ---- grouped 3x3 conv (fp32 kernels) ------------------------------------------------------------------
+    _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads)
+    # ---- ChannelNorm + FiLM, residual ---------------------------------------------------------------------
+    film = sv["film"]
+    dfilm16 = _e16(film.shape[0], film.shape[1], dev=dev)
+    dx = torch.empty_like(x)
+    dx16 = _e16(m, c, dev=dev)
+    ops.channelnorm_film_bwd_bf16(x, film, ctx.slot, dxf, dy, dx, dx16, dfilm16, b, h * w, c, blk.norm.eps)
+    encodings_backward16(blk.encodings, sv["codes"], sv["enc_hidden"], dfilm16, grads)
+    return dx, dx16
+
+
+def _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads):
+    """data gradient (accumulated into dxf) and weight / bias gradient of the grouped 3x3 conv (unet.py:30,44), fp32."""
+    b, h, w = shape
+    m, c = xf.shape
+    dev = xf.device
+    g = c // 32
+    wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
+    wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
+    ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
+             cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
+    dwconv = torch.empty(g, 32, 288, device=dev, dtype=torch.float32)
+    sp = _gconv_splits(g, m) if 2 <= w <= 96 else 0
+    if sp:
+        planes = torch.empty(4 * sp, c, 288, device=dev, dtype=torch.float32)
+        ops.gconv3x3_wgrad(xf, dy, planes, b, h, w, c, sp)
+        ops.reduce_partials(planes, 4 * sp, c * 288, dwconv)
+    else:
+        dy_t = _T(dy)
+        xcol_t = torch.empty(g, 288, m, device=dev, dtype=torch.float32)
+        ops.im2col3x3_t(xf, xcol_t, b, h, w, c)
+        for gi in range(g):
+            dwconv[gi] = grad_weight(dy_t[gi * 32:(gi + 1) * 32], xcol_t[gi], m)
+    grads.add(blk.conv.weight, dwconv.reshape(c, 3, 3, 32).permute(0, 3, 1, 2))
+    grads.add(blk.conv.bias, bias_dy.clone())
+
+
+# ------------------------------------------------------------------------------------------------------
 # whole UNet
 # ------------------------------------------------------------------------------------------------------
 class UNetFunction(torch.autograd.Function):
@@ -327,14 +545,26 @@ class UNetFunction(torch.autograd.Function):
         rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
         ops.stem_nchw(x, _w2d(net.encoder_first.weight), net.encoder_first.bias.detach(), rows, b, cin, h * w, c0)
 
+        bf16 = getattr(net, "train_precision", "f32") == "bf16"
+        if bf16 and any(ch % 64 for ch in net.channels):
+            raise ValueError("bf16 training needs every stage width to be a multiple of 64 (got %r)" % (net.channels,))
+        codes16 = {}
+
         def run_stage(stage, rows, shape):
             for blk in stage.blocks:
                 picks = decisions[blk]
                 if picks is None:
                     continue
                 codes = ctx.codes(rows.shape[1], shape[1], shape[2])
-                enc_hidden, film = encodings_forward(blk.encodings, codes)
-                rows, sv = block_forward(blk, rows, shape, ctx, picks, film, codes, enc_hidden)
+                if bf16:
+                    key = (rows.shape[1], shape[1], shape[2])
+                    if key not in codes16:                      # one cast per level, shared by its blocks
+                        codes16[key] = ops.cast_bf16(codes)
+                    enc_hidden, film = encodings_forward16(blk.encodings, codes16[key])
+                    rows, sv = block_forward16(blk, rows, shape, ctx, picks, film, codes16[key], enc_hidden)
+                else:
+                    enc_hidden, film = encodings_forward(blk.encodings, codes)
+                    rows, sv = block_forward(blk, rows, shape, ctx, picks, film, codes, enc_hidden)
                 tape.append(("block", sv))
             return rows
 
@@ -366,7 +596,7 @@ class UNetFunction(torch.autograd.Function):
         out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
         wl = net.decoder_last.weight.detach().reshape(c0, cin)
         ops.head_nchw(rows, wl, net.decoder_last.bias.detach(), out, b, c0, h * w, cin)
-        fctx.net, fctx.tape, fctx.tctx, fctx.x, fctx.last_rows, fctx.params = net, tape, ctx, x, rows, params
+        fctx.net, fctx.tape, fctx.tctx, fctx.x, fctx.last_rows, fctx.params, fctx.bf16 = net, tape, ctx, x, rows, params, bf16
         return out
 
     @staticmethod
@@ -384,9 +614,19 @@ class UNetFunction(torch.autograd.Function):
         grads.add(net.decoder_last.weight, dwl)
         grads.add(net.decoder_last.bias, dbl)
         dskip = {}
+        drows16 = None                                       # bf16 shadow of drows (bf16 mode): produced by the block that wrote drows
         for kind, sv in reversed(tape):
             if kind == "block":
-                drows = block_backward(sv, drows, ctx, grads)
+                if fctx.bf16:
+                    if drows16 is None:
+                        drows16 = ops.cast_bf16(drows)
+                    drows, drows16 = block_backward16(sv, drows, drows16, ctx, grads)
+                else:
+                    drows = block_backward(sv, drows, ctx, grads)
+                continue
+            drows16 = None
+            if kind == "block":
+                pass
             elif kind == "up":
                 conv, lo, (bb, lh, lw) = sv["conv"], sv["lo"], sv["shape"]
                 cn = conv.weight.shape[0]
