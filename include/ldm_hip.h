@@ -298,6 +298,17 @@ int ldm_channelnorm_film_bf16(const float *x, const float *film, const int *slot
 int ldm_channelnorm_film_bwd_bf16(const float *x, const float *film, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
                                   void *dfilm_bf16, int B, int HW, int C, float eps, void *stream);
 
+/* Encodings.proj1 in separable form for the training step (unet.py:18-20 with one timestep per sample): the input of proj1 is
+ * cat[pe(pixel), te(t_b)], so proj1(cat) = P[pixel] + T[b] with P = W1[:, :C] pe [HW, N] and T = W1[:, C:] te + b1 [B, N]
+ * (two small GEMMs, N = 4C).  ldm_film_hidden: out[b, pixel, :] = relu(P[pixel] + T[b]) as fp32 or bf16 [B*HW, N].
+ * ldm_film_hidden_bwd: dhm = dh * (hid > 0); partial planes dP_part[z][HW][N] (z < zchunks: sample chunks, summed by the
+ * caller) and dT_part[ceil(HW/32)][B][N] (pixel tiles, summed by the caller); dh / hid fp32 or bf16 (is_bf16); N % 64 == 0.
+ * ldm_film_hidden_bwd_chunks returns the zchunks that fills the chip. */
+int ldm_film_hidden(const float *P, const float *T, void *out, int out_bf16, int B, int HW, int N, void *stream);
+int ldm_film_hidden_bwd_chunks(int B, int HW, int N);
+int ldm_film_hidden_bwd(const void *dh, const void *hid, int is_bf16, float *dP_part, float *dT_part, int B, int HW, int N, int zchunks,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

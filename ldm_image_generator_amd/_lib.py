@@ -132,6 +132,9 @@ SIGNATURES = {
     "ldm_relu_bwd_bf16": (_I, [_P, _P, _P, _L, _P]),
     "ldm_channelnorm_film_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_channelnorm_film_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_film_hidden_bwd_chunks": (_I, [_I, _I, _I]),
+    "ldm_film_hidden_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

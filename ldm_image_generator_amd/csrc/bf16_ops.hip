@@ -327,3 +327,164 @@ extern "C" int ldm_channelnorm_film_bwd_bf16(const float *x, const float *film, 
     LDM_CHECK_LAUNCH("ldm_channelnorm_film_bwd_bf16");
     return LDM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Encodings.proj1 in separable form (unet.py:18-20, training: one timestep per sample).  The input of proj1 is
+// cat[pe(pixel), te(t_b)], so  proj1(cat) = W1[:, :C] pe(pixel) + W1[:, C:] te(t_b) + b1 = P[pixel] + T[b]:  two small GEMMs
+// (HW and B rows) instead of one over B*HW rows -- 16 of the ~55 M*C^2 multiply-adds per pixel of a SwinBlock's forward.
+//   forward : hid[b, pixel, :] = relu(P[pixel, :] + T[b, :])                                            (ldm_film_hidden)
+//   backward: dhm = dh * (hid > 0);  dP[pixel] = sum_b dhm;  dT[b] = sum_pixel dhm                       (ldm_film_hidden_bwd)
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <bool OBF>
+__global__ void film_hidden_kernel(const f32x4 *__restrict__ P, const f32x4 *__restrict__ Tt, void *__restrict__ out, int B, int HW, int n8)
+{
+    // one thread = 8 consecutive columns of one (sample, pixel) row
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * HW * n8;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % n8);
+    const long long row = idx / n8;
+    const int pix = (int)(row % HW), b = (int)(row / HW);
+    const f32x4 p0 = P[((long long)pix * n8 + c8) * 2], p1 = P[((long long)pix * n8 + c8) * 2 + 1];
+    const f32x4 t0 = Tt[((long long)b * n8 + c8) * 2], t1 = Tt[((long long)b * n8 + c8) * 2 + 1];
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o0[e] = fmaxf(p0[e] + t0[e], 0.f);
+        o1[e] = fmaxf(p1[e] + t1[e], 0.f);
+    }
+    if constexpr (OBF) {
+        ((u32x4 *)out)[idx] = u32x4{pack2(o0[0], o0[1]), pack2(o0[2], o0[3]), pack2(o1[0], o1[1]), pack2(o1[2], o1[3])};
+    } else {
+        ((f32x4 *)out)[2 * idx] = o0;
+        ((f32x4 *)out)[2 * idx + 1] = o1;
+    }
+}
+
+// One WAVE owns 32 pixels x 64 columns and a range of samples: lane = (pixel & 7) * 8 + column chunk (8 columns), four
+// sub-tiles of 8 pixels.  dP accumulates in registers over the samples; dT over the wave's 32 pixels (4 sub-tiles in
+// registers, then 3 xor-shuffle steps over the pixel lanes).  No barriers, no atomics; partial planes
+//   dP_part[z][HW][N] (z = sample chunk),  dT_part[pixel tile][B][N]   are summed by the caller in a fixed order.
+template <bool BF>
+__global__ __launch_bounds__(256) void film_hidden_bwd_kernel(const void *__restrict__ dh, const void *__restrict__ hid, float *__restrict__ dP_part,
+                                                              float *__restrict__ dT_part, int B, int HW, int N, int ptiles, int bchunk)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);            // global wave id over (pixel tile, column group)
+    const int ngroups = N >> 6;
+    if (gw >= ptiles * ngroups) return;
+    const int tile = gw / ngroups, grp = gw - tile * ngroups;
+    const int z = blockIdx.y;
+    const int b0 = z * bchunk, b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
+    const int psub = lane >> 3, chunk = lane & 7;
+    const int col = grp * 64 + chunk * 8;
+    float accP[4][8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accP[s][e] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        float accT[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accT[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pix = tile * 32 + s * 8 + psub;
+            float v[8];
+            if (pix < HW) {
+                const long long off = ((long long)b * HW + pix) * N + col;
+                if constexpr (BF) {
+                    const u32x4 g = *(const u32x4 *)((const unsigned short *)dh + off);
+                    const u32x4 y = *(const u32x4 *)((const unsigned short *)hid + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = lo16(y[e]) > 0.f ? lo16(g[e]) : 0.f;
+                        v[2 * e + 1] = hi16(y[e]) > 0.f ? hi16(g[e]) : 0.f;
+                    }
+                } else {
+                    const f32x4 g0 = *(const f32x4 *)((const float *)dh + off), g1 = *(const f32x4 *)((const float *)dh + off + 4);
+                    const f32x4 y0 = *(const f32x4 *)((const float *)hid + off), y1 = *(const f32x4 *)((const float *)hid + off + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = y0[e] > 0.f ? g0[e] : 0.f;
+                        v[4 + e] = y1[e] > 0.f ? g1[e] : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                accP[s][e] += v[e];
+                accT[e] += v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = accT[e];
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            accT[e] = t;
+        }
+        if (psub == 0) {
+            float *dst = dT_part + ((long long)tile * B + b) * N + col;
+            *(f32x4 *)dst = f32x4{accT[0], accT[1], accT[2], accT[3]};
+            *(f32x4 *)(dst + 4) = f32x4{accT[4], accT[5], accT[6], accT[7]};
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pix = tile * 32 + s * 8 + psub;
+        if (pix < HW) {
+            float *dst = dP_part + ((long long)z * HW + pix) * N + col;
+            *(f32x4 *)dst = f32x4{accP[s][0], accP[s][1], accP[s][2], accP[s][3]};
+            *(f32x4 *)(dst + 4) = f32x4{accP[s][4], accP[s][5], accP[s][6], accP[s][7]};
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ldm_film_hidden(const float *P, const float *T, void *out, int out_bf16, int B, int HW, int N, void *stream)
+{
+    LDM_REQUIRE(P && T && out && B > 0 && HW > 0 && N > 0 && N % 8 == 0, "ldm_film_hidden: bad arguments (N %% 8 == 0)");
+    LDM_REQUIRE(ldm_aligned16(P) && ldm_aligned16(T) && ldm_aligned16(out), "ldm_film_hidden: unaligned pointer");
+    const long long total = (long long)B * HW * (N / 8);
+    if (out_bf16)
+        hipLaunchKernelGGL(film_hidden_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)P, (const f32x4 *)T, out, B, HW, N / 8);
+    else
+        hipLaunchKernelGGL(film_hidden_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)P, (const f32x4 *)T, out, B, HW, N / 8);
+    LDM_CHECK_LAUNCH("ldm_film_hidden");
+    return LDM_OK;
+}
+
+extern "C" int ldm_film_hidden_bwd_chunks(int B, int HW, int N)
+{
+    // sample chunks (grid.y): enough waves to fill the chip (>= ~2048) without more partial planes than needed
+    const long long waves = (long long)((HW + 31) / 32) * (N / 64);
+    int z = 1;
+    while (waves * z < 2048 && z * 2 <= B && z < 32) z *= 2;
+    return z;
+}
+
+extern "C" int ldm_film_hidden_bwd(const void *dh, const void *hid, int is_bf16, float *dP_part, float *dT_part, int B, int HW, int N, int zchunks,
+                                   void *stream)
+{
+    LDM_REQUIRE(dh && hid && dP_part && dT_part && B > 0 && HW > 0 && N >= 64 && N % 64 == 0 && zchunks >= 1 && zchunks <= 65535,
+                "ldm_film_hidden_bwd: bad arguments (N %% 64 == 0)");
+    LDM_REQUIRE(ldm_aligned16(dh) && ldm_aligned16(hid) && ldm_aligned16(dP_part) && ldm_aligned16(dT_part), "ldm_film_hidden_bwd: unaligned pointer");
+    const int ptiles = (HW + 31) / 32;
+    const long long waves = (long long)ptiles * (N / 64);
+    const int bchunk = (B + zchunks - 1) / zchunks;
+    dim3 grid(blocks_for(waves, 4), zchunks);
+    if (is_bf16)
+        hipLaunchKernelGGL(film_hidden_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dh, hid, dP_part, dT_part, B, HW, N, ptiles, bchunk);
+    else
+        hipLaunchKernelGGL(film_hidden_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dh, hid, dP_part, dT_part, B, HW, N, ptiles, bchunk);
+    LDM_CHECK_LAUNCH("ldm_film_hidden_bwd");
+    return LDM_OK;
+}

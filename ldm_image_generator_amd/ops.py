@@ -415,3 +415,25 @@ def channelnorm_film_bwd_bf16(x, film, slot, dxf, dres, dx, dx_bf16, dfilm_bf16,
 def uncast_bf16(x, out):
     _call("ldm_uncast_bf16", _dev(x, "x", BF16), _dev(out, "out"), x.numel())
     return out
+
+
+def film_hidden(p_rows, t_rows, out, B, HW, N):
+    """out[b, pixel, :] = relu(P[pixel] + T[b]) -- Encodings.proj1 in separable form; ``out`` fp32 or bf16 [B*HW, N]."""
+    bf = out.dtype == BF16
+    _call("ldm_film_hidden", _dev(p_rows, "P"), _dev(t_rows, "T"), _dev(out, "out", BF16 if bf else torch.float32), int(bf), B, HW, N)
+    return out
+
+
+def film_hidden_bwd(dh, hid, B, HW, N):
+    """-> (dP [HW, N], dT [B, N]) fp32: the sums over samples / over pixels of dh * (hid > 0); dh, hid fp32 or bf16."""
+    bf = dh.dtype == BF16
+    dt = BF16 if bf else torch.float32
+    z = _lib.load().ldm_film_hidden_bwd_chunks(B, HW, N)
+    ptiles = (HW + 31) // 32
+    dev = dh.device
+    dp_part = torch.empty(z, HW, N, device=dev, dtype=torch.float32)
+    dt_part = torch.empty(ptiles, B, N, device=dev, dtype=torch.float32)
+    _call("ldm_film_hidden_bwd", _dev(dh, "dh", dt), _dev(hid, "hid", dt), int(bf), _dev(dp_part, "dP_part"), _dev(dt_part, "dT_part"), B, HW, N, z)
+    dp = dp_part[0] if z == 1 else reduce_partials(dp_part, z, HW * N, torch.empty(HW, N, device=dev, dtype=torch.float32))
+    dtt = dt_part[0] if ptiles == 1 else reduce_partials(dt_part, ptiles, B * N, torch.empty(B, N, device=dev, dtype=torch.float32))
+    return dp, dtt

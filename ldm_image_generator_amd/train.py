@@ -277,34 +277,78 @@ def block_backward(sv, dy, ctx, grads):
     return dx
 
 
-def encodings_forward(enc, codes):
-    """unet.py:20 keeping the hidden activation.  codes [Mf, 2C] (Mf padded to a multiple of 32 with zero rows)."""
-    m, c = codes.shape[0], enc.channels
-    hid = torch.empty(m, 4 * c, device=codes.device, dtype=torch.float32)
-    ops.gemm(codes, m, 4 * c, 2 * c, [_w2d(enc.proj1.weight)], hid, biases=[enc.proj1.bias.detach()], act=ops.ACT_RELU)
-    film = torch.empty(m, 2 * c, device=codes.device, dtype=torch.float32)
-    ops.gemm(hid, m, 2 * c, 4 * c, [_w2d(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
+class LevelCodes:
+    """The sin / cos codes of one UNet level for the training step: position part [HW, C] and time part [B, C] (one timestep per
+    sample), generated once and shared by the level's SwinBlocks.  Encodings.proj1 is applied to cat[pe(pixel), te(t_b)]
+    (unet.py:18-20), so its pre-activation is separable: P[pixel] + T[b]."""
+
+    def __init__(self, ctx, channels, height, width):
+        from . import sinusoidal
+        t = ctx.t_unique
+        self.b, self.hw, self.c = t.numel(), height * width, channels
+        self.pe = sinusoidal.embed(t[:1], height, width, channels)[:, :channels].contiguous()          # [HW, C]
+        self.te = sinusoidal.embed(t, 1, 1, channels)[:, channels:].contiguous()                       # [B, C]
+
+
+def _pad_rows(t, mult=32):
+    m = t.shape[0]
+    mp = (m + mult - 1) // mult * mult
+    if mp == m:
+        return t, m
+    out = torch.zeros(mp, t.shape[1], device=t.device, dtype=t.dtype)
+    out[:m] = t
+    return out, mp
+
+
+def _grad_weight_small(dy, x):
+    """dW [N, K] = dy^T x for SHORT fp32 operands (HW or B rows): zero-padded to a multiple of 32 rows."""
+    dy, mp = _pad_rows(dy)
+    x, _ = _pad_rows(x)
+    return grad_weight_rows(_Rows(dy), _Rows(x), mp)
+
+
+def encodings_forward(enc, lc, bf16=False):
+    """unet.py:20 for one timestep per sample, keeping the hidden activation: hid = relu(P[pixel] + T[b]) with
+    P = W1[:, :C] pe, T = W1[:, C:] te + b1 (fp32, tiny), film = proj2(hid).  -> (hid [B*HW, 4C] fp32 | bf16, film fp32)."""
+    c, n = enc.channels, 4 * enc.channels
+    dev = lc.pe.device
+    w1 = _w2d(enc.proj1.weight)                                                    # [4C, 2C]: position columns | time columns
+    p_rows = torch.empty(lc.hw, n, device=dev, dtype=torch.float32)
+    ops.gemm(lc.pe, lc.hw, n, c, [w1], p_rows, ldw=2 * c)
+    t_rows = torch.empty(lc.b, n, device=dev, dtype=torch.float32)
+    ops.gemm(lc.te, lc.b, n, c, [w1.reshape(-1)[c:]], t_rows, ldw=2 * c, biases=[enc.proj1.bias.detach()])
+    m = lc.b * lc.hw
+    hid = torch.empty(m, n, device=dev, dtype=BF16 if bf16 else torch.float32)
+    ops.film_hidden(p_rows, t_rows, hid, lc.b, lc.hw, n)
+    film = torch.empty(m, 2 * c, device=dev, dtype=torch.float32)
+    if bf16:
+        ops.gemm_bf16(hid, m, 2 * c, n, [W16.get(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
+    else:
+        ops.gemm(hid, m, 2 * c, n, [_w2d(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
     return hid, film
 
 
-def encodings_backward(enc, codes, hid, dfilm, grads):
-    m, c = codes.shape[0], enc.channels
-    mp = (m + 31) // 32 * 32
-    if mp != m:           # pad the (small) FiLM-side matrices with zero rows so the reduction length is a multiple of 32
-        def pad(t):
-            out = torch.zeros(mp, t.shape[1], device=t.device, dtype=torch.float32)
-            out[:m] = t
-            return out
-        codes, hid, dfilm = pad(codes), pad(hid), pad(dfilm)
-    dfilm_r = _Rows(dfilm)
-    grads.add(enc.proj2.weight, grad_weight_rows(dfilm_r, _Rows(hid), mp))
-    grads.add(enc.proj2.bias, dfilm_r.colsum())
-    dh = torch.empty(mp, 4 * c, device=codes.device, dtype=torch.float32)
-    ops.gemm(dfilm, mp, 4 * c, 2 * c, [WT.get(_w2d(enc.proj2.weight), enc.proj2.weight)], dh)
-    ops.relu_bwd(dh, hid, dh)
-    dh_r = _Rows(dh)
-    grads.add(enc.proj1.weight, grad_weight_rows(dh_r, _Rows(codes), mp))
-    grads.add(enc.proj1.bias, dh_r.colsum())
+def encodings_backward(enc, lc, hid, dfilm, grads):
+    """Gradients of proj2 (GEMM-shaped) and of proj1 through its separable form: dP = sum over samples, dT = sum over pixels of
+    dh * (hid > 0) (one pass over dh), then dW1 = [dP^T pe | dT^T te], db1 = sum_b dT."""
+    c, n = enc.channels, 4 * enc.channels
+    m = lc.b * lc.hw
+    dev = hid.device
+    if hid.dtype == BF16:
+        dw2, db2 = grad_weight_rows16(dfilm, hid, m)
+        dh = _e16(m, n, dev=dev)
+        ops.gemm_bf16(dfilm, m, n, 2 * c, [W16.get(enc.proj2.weight, True)], dh)
+    else:
+        dfilm_r = _Rows(dfilm)
+        dw2 = grad_weight_rows(dfilm_r, _Rows(hid), m)
+        db2 = dfilm_r.colsum()
+        dh = torch.empty(m, n, device=dev, dtype=torch.float32)
+        ops.gemm(dfilm, m, n, 2 * c, [WT.get(_w2d(enc.proj2.weight), enc.proj2.weight)], dh)
+    grads.add(enc.proj2.weight, dw2)
+    grads.add(enc.proj2.bias, db2)
+    dp, dt = ops.film_hidden_bwd(dh, hid, lc.b, lc.hw, n)
+    grads.add(enc.proj1.weight, torch.cat([_grad_weight_small(dp, lc.pe), _grad_weight_small(dt, lc.te)], dim=1))
+    grads.add(enc.proj1.bias, ops.colsum(dt, lc.b, n))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -384,29 +428,6 @@ def grad_weight_rows16(dy16, x16, m_red, want_colsum=True):
     if want_colsum:
         cs = ops.reduce_partials(cs, s, n_out, torch.empty(n_out, device=dev, dtype=torch.float32))
     return out, cs
-
-
-def encodings_forward16(enc, codes16):
-    m, c = codes16.shape[0], enc.channels
-    dev = codes16.device
-    hid = _e16(m, 4 * c, dev=dev)
-    ops.gemm_bf16(codes16, m, 4 * c, 2 * c, [W16.get(enc.proj1.weight)], hid, biases=[enc.proj1.bias.detach()], act=ops.ACT_RELU)
-    film = torch.empty(m, 2 * c, device=dev, dtype=torch.float32)
-    ops.gemm_bf16(hid, m, 2 * c, 4 * c, [W16.get(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
-    return hid, film
-
-
-def encodings_backward16(enc, codes16, hid16, dfilm16, grads):
-    m, c = codes16.shape[0], enc.channels
-    dw2, db2 = grad_weight_rows16(dfilm16, hid16, m)
-    grads.add(enc.proj2.weight, dw2)
-    grads.add(enc.proj2.bias, db2)
-    dh = _e16(m, 4 * c, dev=codes16.device)
-    ops.gemm_bf16(dfilm16, m, 4 * c, 2 * c, [W16.get(enc.proj2.weight, True)], dh)
-    ops.relu_bwd_bf16(dh, hid16, dh)
-    dw1, db1 = grad_weight_rows16(dh, codes16, m)
-    grads.add(enc.proj1.weight, dw1)
-    grads.add(enc.proj1.bias, db1)
 
 
 def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
@@ -495,7 +516,7 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     dx = torch.empty_like(x)
     dx16 = _e16(m, c, dev=dev)
     ops.channelnorm_film_bwd_bf16(x, film, ctx.slot, dxf, dy, dx, dx16, dfilm16, b, h * w, c, blk.norm.eps)
-    encodings_backward16(blk.encodings, sv["codes"], sv["enc_hidden"], dfilm16, grads)
+    encodings_backward(blk.encodings, sv["codes"], sv["enc_hidden"], dfilm16, grads)
     return dx, dx16
 
 
@@ -548,23 +569,20 @@ class UNetFunction(torch.autograd.Function):
         bf16 = getattr(net, "train_precision", "f32") == "bf16"
         if bf16 and any(ch % 64 for ch in net.channels):
             raise ValueError("bf16 training needs every stage width to be a multiple of 64 (got %r)" % (net.channels,))
-        codes16 = {}
+        level_codes = {}
 
         def run_stage(stage, rows, shape):
             for blk in stage.blocks:
                 picks = decisions[blk]
                 if picks is None:
                     continue
-                codes = ctx.codes(rows.shape[1], shape[1], shape[2])
-                if bf16:
-                    key = (rows.shape[1], shape[1], shape[2])
-                    if key not in codes16:                      # one cast per level, shared by its blocks
-                        codes16[key] = ops.cast_bf16(codes)
-                    enc_hidden, film = encodings_forward16(blk.encodings, codes16[key])
-                    rows, sv = block_forward16(blk, rows, shape, ctx, picks, film, codes16[key], enc_hidden)
-                else:
-                    enc_hidden, film = encodings_forward(blk.encodings, codes)
-                    rows, sv = block_forward(blk, rows, shape, ctx, picks, film, codes, enc_hidden)
+                key = (rows.shape[1], shape[1], shape[2])
+                if key not in level_codes:                      # one code table per level, shared by its blocks
+                    level_codes[key] = LevelCodes(ctx, *key)
+                lc = level_codes[key]
+                enc_hidden, film = encodings_forward(blk.encodings, lc, bf16)
+                fwd = block_forward16 if bf16 else block_forward
+                rows, sv = fwd(blk, rows, shape, ctx, picks, film, lc, enc_hidden)
                 tape.append(("block", sv))
             return rows
 

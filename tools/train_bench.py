@@ -17,12 +17,15 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--latent", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--gemm-variant", type=int, default=1, help="1 = exact-fp32 stream schedule, 2 = bf16x3 split consumer")
+ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="operand precision of the training step (train.set_precision)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 ops.gemm_variant(args.gemm_variant)
 net = UNet()
 net.load_state_dict(synth.fill_state_dict(net.state_dict()))
 net = net.to(dev).train()
+from ldm_image_generator_amd import train as ltrain  # noqa: E402
+ltrain.set_precision(net, args.precision)
 ddpm = DDPM(model=net)
 opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)
 x = torch.randn(args.batch, 8, args.latent, args.latent, generator=torch.Generator().manual_seed(0)).to(dev)
