@@ -309,6 +309,19 @@ int ldm_film_hidden_bwd_chunks(int B, int HW, int N);
 int ldm_film_hidden_bwd(const void *dh, const void *hid, int is_bf16, float *dP_part, float *dT_part, int B, int HW, int N, int zchunks,
                         void *stream);
 
+/* All bf16 weight copies of a training step in one launch: job j = fp32 row-major [rows, cols] -> bf16 copy `dst` [rows, cols]
+ * and / or transposed bf16 copy `dst_t` [cols, rows] (NULL = not wanted).  `items` is a HOST array; `table_dev` a DEVICE scratch
+ * of ldm_multi_cast_table_bytes(njobs) that holds the uploaded job table between calls: pass rebuild != 0 on the first call and
+ * whenever a pointer or shape changed, 0 otherwise (*tiles_io carries the grid size between calls). */
+typedef struct ldm_cast_job {
+    const float *src;
+    void        *dst, *dst_t;
+    long long    rows;
+    int          cols;
+} ldm_cast_job;
+size_t ldm_multi_cast_table_bytes(int njobs);
+int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, int rebuild, long long *tiles_io, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

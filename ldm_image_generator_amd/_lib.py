@@ -73,6 +73,11 @@ class UNetPlanDesc(ctypes.Structure):
                 ("blocks", ctypes.POINTER(UNetBlockDesc))]
 
 
+class CastJob(ctypes.Structure):
+    """struct ldm_cast_job"""
+    _fields_ = [("src", c_fp), ("dst", c_fp), ("dst_t", c_fp), ("rows", ctypes.c_longlong), ("cols", ctypes.c_int)]
+
+
 _I, _L, _F, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
 
 # name -> (restype, argtypes); every symbol declared in include/ldm_hip.h
@@ -132,6 +137,8 @@ SIGNATURES = {
     "ldm_relu_bwd_bf16": (_I, [_P, _P, _P, _L, _P]),
     "ldm_channelnorm_film_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_channelnorm_film_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_multi_cast_table_bytes": (ctypes.c_size_t, [_I]),
+    "ldm_multi_cast_bf16": (_I, [ctypes.POINTER(CastJob), _I, _P, _I, ctypes.POINTER(_L), _P]),
     "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_film_hidden_bwd_chunks": (_I, [_I, _I, _I]),
     "ldm_film_hidden_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

@@ -3,6 +3,7 @@
 // reductions, fp32 arithmetic inside.  The residual stream, its gradient, FiLM rows and all parameter gradients stay fp32.
 #include "common.h"
 #include <cmath>
+#include <vector>
 
 namespace {
 
@@ -486,5 +487,83 @@ extern "C" int ldm_film_hidden_bwd(const void *dh, const void *hid, int is_bf16,
     else
         hipLaunchKernelGGL(film_hidden_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dh, hid, dP_part, dT_part, B, HW, N, ptiles, bchunk);
     LDM_CHECK_LAUNCH("ldm_film_hidden_bwd");
+    return LDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// All bf16 weight copies of a training step in ONE launch (master weights are fp32 and change every optimizer step): job j is
+// a row-major fp32 matrix [rows, cols]; the kernel writes bf16(W) [rows, cols] and bf16(W^T) [cols, rows] (either may be
+// absent).  One workgroup = one 64 x 64 tile of one job, found by binary search in the tile prefix sums of the device-side
+// job table.  ~300 launches of 8-10 us (mostly launch-bound, 5 ms per step) become one bandwidth-bound pass (< 1 ms).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct CastJobDev {
+    const float *src;
+    unsigned short *dst, *dst_t;
+    int rows, cols, tiles_c;
+    int pad;
+    long long tile0;          // first tile id of this job
+};
+
+__global__ __launch_bounds__(256) void multi_cast_kernel(const CastJobDev *__restrict__ jobs, int njobs)
+{
+    __shared__ float tile[64][65];
+    const long long tid = blockIdx.x;
+    int lo = 0, hi = njobs - 1;                          // last job with tile0 <= tid
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= tid) lo = mid; else hi = mid - 1;
+    }
+    const CastJobDev j = jobs[lo];
+    const int t = (int)(tid - j.tile0);
+    const int r0 = (t / j.tiles_c) * 64, c0 = (t % j.tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        const float v = (r < j.rows && c < j.cols) ? j.src[(long long)r * j.cols + c] : 0.f;
+        tile[i][tx] = v;
+        if (j.dst && r < j.rows && c < j.cols) j.dst[(long long)r * j.cols + c] = (unsigned short)(pack2(v, 0.f) & 0xFFFFu);
+    }
+    if (!j.dst_t) return;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < j.cols && r < j.rows) j.dst_t[(long long)c * j.rows + r] = (unsigned short)(pack2(tile[tx][i], 0.f) & 0xFFFFu);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ldm_multi_cast_table_bytes(int njobs) { return (size_t)njobs * sizeof(CastJobDev); }
+
+/* items: HOST array of njobs (src, dst, dst_t, rows, cols); table_dev: DEVICE scratch of ldm_multi_cast_table_bytes(njobs).
+ * rebuild != 0 uploads the job table first (needed once, and again only when a pointer or shape changed); returns the tile
+ * count through *tiles_io (pass the value back on later calls with rebuild == 0). */
+extern "C" int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, int rebuild, long long *tiles_io, void *stream)
+{
+    LDM_REQUIRE(items && njobs > 0 && table_dev && tiles_io, "ldm_multi_cast_bf16: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (rebuild) {
+        std::vector<CastJobDev> tab((size_t)njobs);
+        long long tiles = 0;
+        for (int i = 0; i < njobs; ++i) {
+            LDM_REQUIRE(items[i].src && items[i].rows > 0 && items[i].cols > 0 && (items[i].dst || items[i].dst_t), "ldm_multi_cast_bf16: bad job %d", i);
+            tab[i].src = items[i].src; tab[i].dst = (unsigned short *)items[i].dst; tab[i].dst_t = (unsigned short *)items[i].dst_t;
+            tab[i].rows = (int)items[i].rows; tab[i].cols = items[i].cols; tab[i].tiles_c = (items[i].cols + 63) / 64; tab[i].pad = 0;
+            tab[i].tile0 = tiles;
+            tiles += (long long)((items[i].rows + 63) / 64) * tab[i].tiles_c;
+        }
+        LDM_REQUIRE(tiles > 0 && tiles <= 0x7fffffffLL, "ldm_multi_cast_bf16: too many tiles");
+        // pageable host memory: hipMemcpyAsync returns once the staging copy is done, so `tab` may go out of scope
+        if (hipMemcpyAsync(table_dev, tab.data(), tab.size() * sizeof(CastJobDev), hipMemcpyHostToDevice, st) != hipSuccess) {
+            ldm_set_error("ldm_multi_cast_bf16: table upload failed");
+            return LDM_ELAUNCH;
+        }
+        *tiles_io = tiles;
+    }
+    LDM_REQUIRE(*tiles_io > 0, "ldm_multi_cast_bf16: table was never built");
+    hipLaunchKernelGGL(multi_cast_kernel, dim3((unsigned)*tiles_io), dim3(256), 0, st, (const CastJobDev *)table_dev, njobs);
+    LDM_CHECK_LAUNCH("ldm_multi_cast_bf16");
     return LDM_OK;
 }

@@ -61,11 +61,14 @@ extern "C" int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream)
 // ------------------------------------------------------------------------------------------------------------------------
 // TN: out[s][n][k] = sum over rows m of split s of A[m][n] * B[m][k]   (dW = dY^T X, autograd of every 1x1 conv / Linear)
 //
-// Stage = [BR = 64 rows][128 columns] bf16 of each operand (256-byte LDS rows, 16 chunks of 16 B), filled by LDS-DMA as the
-// rows lie in memory.  The MFMA wants, per lane, 8 consecutive m of ONE column: two ds_read_b64_tr_b16 (each hands a lane
-// 4 rows of its column out of a 4 x 16 block read by 16 lanes).  Chunk swizzle on the DMA source side and on the reads:
-// physical chunk = logical ^ (((row & 3) << 2) | ((row >> 2) & 3)), the conflict-free image for transposed 32x32x16 operand reads.
-// 128 x 128 output tile per workgroup, 4 waves of 64 x 64; split over M on the grid, partial planes summed by the caller.
+// Output tile 128 (n) x 128 KT (k) per workgroup, KT = 1 | 2; 4 waves of 64 x 64 KT.  A stage = 32 contraction rows of both
+// operands ([32][128] bf16 sub-tiles with 256-byte LDS rows), filled by LDS-DMA as the rows lie in memory, into a ring of
+// NS = 4 (KT = 1, 16 KB stages) or 3 (KT = 2, 24 KB) stages: the DMA runs NS - 1 stages ahead behind COUNTED vmcnt waits and
+// one raw barrier per stage (the 16 ... 32 MFMAs of a stage are far shorter than an HBM round trip, so a one-stage lookahead
+// left the waves parked 60-70 % of the time).  The MFMA wants, per lane, 8 consecutive m of ONE column: two
+// ds_read_b64_tr_b16 (each hands a lane 4 rows of its column out of a 4 x 16 block read by 16 lanes).  Chunk swizzle on the
+// DMA source side and on the reads: physical chunk = logical ^ (((row & 3) << 2) | ((row >> 2) & 3)) -- conflict-free for the
+// transposed 32x32x16 operand reads.  Split over M on the grid; partial planes summed by the caller in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -73,7 +76,6 @@ typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
 
 struct TnP16 {
@@ -83,16 +85,42 @@ struct TnP16 {
     int M, N, K, ms, splits, ntn, ntk;
 };
 
-constexpr int TBT = 128;             // output tile edge
-constexpr int TBR = 64;              // contraction rows per stage
-constexpr int TSTAGE = 2 * TBR * TBT;   // bf16 elements per stage (A then B)
+constexpr int TBT = 128;             // sub-tile edge (columns of one [32][128] LDS image)
+constexpr int TBR = 32;              // contraction rows per stage
+constexpr int TSUB = TBR * TBT;      // bf16 elements of one sub-tile image
 
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 
+// LDS-DMA from inline asm (16 bytes per lane, destination = wave-uniform LDS byte address + lane * 16).  M0 carries the
+// destination and is compiler-reserved: saved and restored inside the one statement that uses it.
+__device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void tn_wait_vmcnt()
+{
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N < 0, "unsupported count");
+}
+
+template <int KT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
 {
+    constexpr int NS = KT == 1 ? 4 : 3;                 // ring stages
+    constexpr int LOOK = NS - 1;                        // stages in flight
+    constexpr int PW = 2 + 2 * KT;                      // LDS-DMA instructions per wave per stage
+    constexpr int STAGE = (1 + KT) * TSUB;              // bf16 elements per stage: A sub-tile, then KT B sub-tiles
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -107,29 +135,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
         tile = (int)blockIdx.x % T;
         split = (int)blockIdx.x / T;
     }
-    const int n0 = (tile / p.ntk) * TBT, k0 = (tile % p.ntk) * TBT;
+    const int n0 = (tile / p.ntk) * TBT, k0 = (tile % p.ntk) * TBT * KT;
     const long long row0 = (long long)split * p.ms;
     const int nsteps = p.ms / TBR;
 
-    // DMA: one instruction = 64 lanes x 16 B = 4 rows of one operand tile; a wave moves rows 4 (4 i + wave) .. + 3, i < 4
+    // DMA: one instruction = 64 lanes x 16 B = 4 rows of one sub-tile; a wave moves rows 4 (4 i + wave) .. + 3, i < 2, of every sub-tile.
+    // Issued from inline asm: hipcc then does not know that LDS is written behind its back and leaves the counted vmcnt
+    // waits below alone (with the builtin it put s_waitcnt vmcnt(0) in front of the first transposing read of every stage).
     const int drow = lane >> 4, dchunk = lane & 15;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short *)lds16;
     auto issue = [&](int step) {
-        unsigned short *As = lds16 + (step & 1) * TSTAGE, *Bs = As + TBR * TBT;
+        const unsigned dst0 = lds_base + (unsigned)(((step % NS) * STAGE + wave * 512) * 2);       // bytes; + i * 4096 + subtile * 8192
         const long long mbase = row0 + (long long)step * TBR;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int row = 4 * (4 * i + wave) + drow;
             const int csrc = (dchunk ^ tn_swz(row)) * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.a + (mbase + row) * p.lda + n0 + csrc), (lptr_t)(As + (4 * i + wave) * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.b + (mbase + row) * p.ldb + k0 + csrc), (lptr_t)(Bs + (4 * i + wave) * 512), 16, 0, 0);
+            glds16_asm(p.a + (mbase + row) * p.lda + n0 + csrc, __builtin_amdgcn_readfirstlane(dst0 + i * 4096));
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+                glds16_asm(p.b + (mbase + row) * p.ldb + k0 + j * TBT + csrc, __builtin_amdgcn_readfirstlane(dst0 + i * 4096 + (1 + j) * TSUB * 2));
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2 * KT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2 * KT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -149,25 +182,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
 
     const bool want_cs = p.colsum != nullptr && k0 == 0 && wn == 0;      // one workgroup column and one wave column own each A column
     float cs[2] = {0.f, 0.f};            // column sums of A: this lane's column of each of its two A tiles, its 8 rows per 16-row slice
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s0 = 0; s0 < LOOK; ++s0)
+        if (s0 < nsteps) issue(s0);
 #pragma unroll 1
     for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) issue(step + 1);
-        const unsigned short *As = lds16 + (step & 1) * TSTAGE, *Bs = As + TBR * TBT;
+        // this wave's pieces of stage `step` have landed once at most the younger stages' instructions are outstanding
+        const int younger = nsteps - 1 - step < LOOK - 1 ? nsteps - 1 - step : LOOK - 1;
+        if (younger >= 2) tn_wait_vmcnt<2 * PW>();
+        else if (younger == 1) tn_wait_vmcnt<PW>();
+        else tn_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and its reads of the slot about to be refilled are complete
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + LOOK < nsteps) issue(step + LOOK);                  // into the slot every wave finished reading before this barrier
+        const unsigned short *As = lds16 + (step % NS) * STAGE;
 #pragma unroll
         for (int s = 0; s < TBR / 16; ++s) {
-            s16x8 a[2], b[2];
+            s16x8 a[2], b[2 * KT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = frag(As, 16 * s, wm * 64 + 32 * i);
-                b[i] = frag(Bs, 16 * s, wn * 64 + 32 * i);
+            for (int i = 0; i < 2; ++i) a[i] = frag(As, 16 * s, wm * 64 + 32 * i);
+#pragma unroll
+            for (int j = 0; j < 2 * KT; ++j) {
+                const int c = wn * 64 * KT + 32 * j;                    // column inside the workgroup's K range
+                b[j] = frag(As + (1 + c / TBT) * TSUB, 16 * s, c % TBT);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2 * KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             if (want_cs) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -175,8 +218,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
                     for (int e = 0; e < 8; ++e) cs[i] += bf16_lo((unsigned)(unsigned short)a[i][e]);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     const int r = lane & 31, h = lane >> 5;
@@ -188,15 +229,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
         }
     }
     // C/D map: column = lane & 31 (k index), row = (e & 3) + 8 (e >> 2) + 4 h (n index)
-    float *obase = p.out + (long long)split * p.N * p.K + (long long)(n0 + wm * 64) * p.K + k0 + wn * 64 + r;
+    float *obase = p.out + (long long)split * p.N * p.K + (long long)(n0 + wm * 64) * p.K + k0 + wn * 64 * KT + r;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) obase[(long long)row * p.K + 32 * j] = acc[i][j][e];
+            for (int j = 0; j < 2 * KT; ++j) obase[(long long)row * p.K + 32 * j] = acc[i][j][e];
         }
+}
+
+template <int KT>
+void tn_launch(const TnP16 &p, long long blocks, hipStream_t st)
+{
+    constexpr int NS = KT == 1 ? 4 : 3;
+    constexpr size_t smem = (size_t)NS * (1 + KT) * TSUB * sizeof(unsigned short);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)gemm_tn_bf16_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<KT>, dim3((unsigned)blocks), dim3(256), smem, st, p);
 }
 
 }  // namespace
@@ -206,22 +260,20 @@ extern "C" int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, lon
 {
     LDM_REQUIRE(a && b && out, "ldm_gemm_tn_bf16: null pointer");
     LDM_REQUIRE(M > 0 && N > 0 && K > 0 && N % TBT == 0 && K % TBT == 0, "ldm_gemm_tn_bf16: N=%d and K=%d must be multiples of 128", N, K);
-    LDM_REQUIRE(splits >= 1 && M % splits == 0 && (M / splits) % TBR == 0, "ldm_gemm_tn_bf16: M=%d must split into %d runs of a multiple of 64 rows", M, splits);
+    LDM_REQUIRE(splits >= 1 && M % splits == 0 && (M / splits) % 64 == 0, "ldm_gemm_tn_bf16: M=%d must split into %d runs of a multiple of 64 rows", M, splits);
     LDM_REQUIRE(lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldm_aligned16(a) && ldm_aligned16(b),
                 "ldm_gemm_tn_bf16: operands must be 16-byte addressable (lda=%lld ldb=%lld)", lda, ldb);
     TnP16 p{};
     p.a = (const unsigned short *)a; p.b = (const unsigned short *)b; p.out = out; p.colsum = colsum_a; p.lda = lda; p.ldb = ldb;
-    p.M = M; p.N = N; p.K = K; p.ms = M / splits; p.splits = splits; p.ntn = N / TBT; p.ntk = K / TBT;
+    p.M = M; p.N = N; p.K = K; p.ms = M / splits; p.splits = splits; p.ntn = N / TBT;
+    // 128 x 256 tiles where K allows and the grid stays full: a third less operand traffic per output, twice the MFMAs per barrier
+    const bool wide = K % (2 * TBT) == 0 && (long long)(N / TBT) * (K / (2 * TBT)) * splits >= 256;     // at least one workgroup per CU
+    p.ntk = wide ? K / (2 * TBT) : K / TBT;
     const long long blocks = (long long)p.ntn * p.ntk * splits;
     LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_gemm_tn_bf16: grid too large");
-    constexpr size_t smem = 2ull * TSTAGE * sizeof(unsigned short);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
     void *rec = ldm_prof_begin(LDM_PROF_TN_BF16, 2.0 * M * (double)N * K, (hipStream_t)stream, 2.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
+    if (wide) tn_launch<2>(p, blocks, (hipStream_t)stream);
+    else tn_launch<1>(p, blocks, (hipStream_t)stream);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_gemm_tn_bf16");
     return LDM_OK;

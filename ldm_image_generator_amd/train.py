@@ -371,22 +371,71 @@ def set_precision(net, precision):
 
 
 class _Weight16:
-    """bf16 copies of a parameter viewed as [N, K]: as it lies (forward) and transposed [K, N] (data gradients); one cast per
-    parameter version (= per optimizer step)."""
+    """bf16 copies of the GEMM weights viewed as [N, K]: as they lie (forward) and transposed [K, N] (data gradients).
+    Master weights are fp32 and move every optimizer step, so the copies are refreshed once per step -- all of them by ONE
+    launch (ldm_multi_cast_bf16) over a device-side job table that is rebuilt only when a parameter's storage changed."""
 
     def __init__(self):
-        self.cache = {}
+        self.net_id = None
+        self.views = {}                    # id(param) -> (source address, plain view, transposed view)
+        self.lone = {}
+        self.stamp = None
+
+    @staticmethod
+    def _gemm_weights(net):
+        out = []
+        for blk in [b for l in net.encoder_stages for b in l.stage.blocks] + [b for l in net.decoder_stages for b in l.stage.blocks]:
+            for r in [blk.ffn.general] + list(blk.ffn.experts):
+                out += [r.a.weight, r.b.weight, r.c.weight]
+            out.append(blk.encodings.proj2.weight)
+            if blk.attention_flag:
+                att = blk.self_attention.attention
+                out += [att.in_proj_weight, att.out_proj.weight]
+        return out
+
+    def refresh(self, net):
+        """Call once per training-step forward: re-casts every weight if any of them changed since the last call."""
+        import ctypes
+        from . import _lib
+        plist = self._gemm_weights(net)
+        ptrs = tuple(p.data_ptr() for p in plist)
+        stamp = (ptrs, sum(p._version for p in plist))
+        if self.net_id == id(net) and self.stamp == stamp:
+            return
+        lib = _lib.load()
+        rebuild = self.net_id != id(net) or self.stamp is None or self.stamp[0] != ptrs
+        if rebuild:
+            dev = plist[0].device
+            total = sum(p.numel() for p in plist)
+            self.buf = torch.empty(2 * total, device=dev, dtype=BF16)
+            self.items = (_lib.CastJob * len(plist))()
+            self.views = {}
+            off = 0
+            for it, p in zip(self.items, plist):
+                n, k = p.shape[0], p.numel() // p.shape[0]
+                plain = self.buf[off:off + n * k].view(n, k)
+                trans = self.buf[off + n * k:off + 2 * n * k].view(k, n)
+                off += 2 * n * k
+                it.src, it.dst, it.dst_t, it.rows, it.cols = p.data_ptr(), plain.data_ptr(), trans.data_ptr(), n, k
+                self.views[id(p)] = (p.data_ptr(), plain, trans)
+            self.table = torch.empty(lib.ldm_multi_cast_table_bytes(len(plist)), device=dev, dtype=torch.uint8)
+            self.tiles = ctypes.c_longlong(0)
+            self.keep = plist
+        _lib.check(lib.ldm_multi_cast_bf16(self.items, len(plist), self.table.data_ptr(), int(rebuild), ctypes.byref(self.tiles),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_multi_cast_bf16")
+        self.net_id, self.stamp = id(net), stamp
 
     def get(self, p, transposed=False):
+        hit = self.views.get(id(p))
+        if hit is not None and hit[0] == p.data_ptr():                          # a view into the step's table
+            return hit[1 + int(transposed)]
+        # a parameter outside the refreshed network (module-level use, tests): one cast per parameter version
         key = (p.data_ptr(), p._version)
-        hit = self.cache.get(id(p))
-        if hit is None or hit[0] != key:
-            hit = [key, None, None]
-            self.cache[id(p)] = hit
-        if hit[1 + int(transposed)] is None:
-            w = _w2d(p)
-            hit[1 + int(transposed)] = ops.transpose_cast_bf16(w.contiguous()) if transposed else ops.cast_bf16(w.contiguous())
-        return hit[1 + int(transposed)]
+        lone = self.lone.get(id(p))
+        if lone is None or lone[0] != key:
+            w = _w2d(p).contiguous()
+            lone = self.lone[id(p)] = (key, ops.cast_bf16(w), ops.transpose_cast_bf16(w))
+        return lone[1 + int(transposed)]
 
 
 W16 = _Weight16()
@@ -403,6 +452,15 @@ def _uncast(x16):
     return out
 
 
+def tn16_splits(n_out, k_out, m_red):
+    """Splits of the pixel reduction for ldm_gemm_tn_bf16: fill ~512 workgroups of 128 x 256 (K %% 256 == 0) or 128 x 128 tiles."""
+    tiles = (n_out // 128) * (k_out // 256 if k_out % 256 == 0 else k_out // 128)
+    s = 1
+    while tiles * s < 512 and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:
+        s *= 2
+    return s
+
+
 def grad_weight_rows16(dy16, x16, m_red, want_colsum=True):
     """(dW [N, K] fp32, column sums of dy [N] fp32 or None) for bf16 row-major dy [M, N], x [M, K]: the TN bf16 kernel with the
     operands as they lie in memory; layers it does not cover (N or K not a multiple of 128, M not a multiple of 64: tiny test
@@ -413,10 +471,7 @@ def grad_weight_rows16(dy16, x16, m_red, want_colsum=True):
         dy_r = _Rows(_uncast(dy16))
         dw = grad_weight_rows(dy_r, _Rows(_uncast(x16)), m_red)
         return dw, (dy_r.colsum() if want_colsum else None)
-    tiles = (n_out // 128) * (k_out // 128)
-    s = 1
-    while tiles * s < 512 and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:
-        s *= 2
+    s = tn16_splits(n_out, k_out, m_red)
     out = torch.empty(n_out, k_out, device=dev, dtype=torch.float32)
     cs = torch.empty(s, n_out, device=dev, dtype=torch.float32) if want_colsum else None
     if s == 1:
@@ -569,6 +624,8 @@ class UNetFunction(torch.autograd.Function):
         bf16 = getattr(net, "train_precision", "f32") == "bf16"
         if bf16 and any(ch % 64 for ch in net.channels):
             raise ValueError("bf16 training needs every stage width to be a multiple of 64 (got %r)" % (net.channels,))
+        if bf16:
+            W16.refresh(net)
         level_codes = {}
 
         def run_stage(stage, rows, shape):

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ldm_image_generator_amd import ops  # noqa: E402
+from ldm_image_generator_amd import ops, train  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
@@ -52,10 +52,7 @@ for lvl, c in enumerate([128, 256, 512, 1024]):
         del a, w, out
     for name, n, k in [("TN dWa    N=3C K=C", 3 * c, c), ("TN dWc    N=C K=3C", c, 3 * c), ("TN dW2    N=2C K=4C", 2 * c, 4 * c)]:
         dy, x = rnd(m, n), rnd(m, k)
-        tiles = (n // 128) * (k // 128)
-        s = 1
-        while tiles * s < 512 and m % (2 * s) == 0 and (m // (2 * s)) % 64 == 0 and m // (2 * s) >= 256 and s < 256:
-            s *= 2
+        s = train.tn16_splits(n, k, m)
         parts = torch.empty(s, n, k, device=dev)
         cs = torch.empty(s, n, device=dev)
         dt = timed(lambda: ops.gemm_tn_bf16(dy, x, parts, m, n, k, s, colsum=cs))
