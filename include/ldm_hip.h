@@ -309,6 +309,12 @@ int ldm_film_hidden_bwd_chunks(int B, int HW, int N);
 int ldm_film_hidden_bwd(const void *dh, const void *hid, int is_bf16, float *dP_part, float *dT_part, int B, int HW, int N, int zchunks,
                         void *stream);
 
+/* Grouped 3x3 conv of unet.py:30,44 (32 in / 32 out per group, zero pad 1) with bf16 operands, fp32 accumulate:
+ * out[m, :] = conv(x)[m, :] (+ bias) (+ addend[m, :]);  x [B*H*W, C] bf16, w [C][9][32] bf16 (ldm_gemm_f32's packed grouped
+ * layout: output channel, tap, input channel), bias [C] / addend [B*H*W, C] fp32 or NULL, out fp32 (may alias addend).
+ * The data gradient is the same call on dy with the flipped, in/out-swapped filter. */
+int ldm_gconv3x3_bf16(const void *x, const void *w, const float *bias, const float *addend, float *out, int B, int H, int W, int C, void *stream);
+
 /* All bf16 weight copies of a training step in one launch: job j = fp32 row-major [rows, cols] -> bf16 copy `dst` [rows, cols]
  * and / or transposed bf16 copy `dst_t` [cols, rows] (NULL = not wanted).  `items` is a HOST array; `table_dev` a DEVICE scratch
  * of ldm_multi_cast_table_bytes(njobs) that holds the uploaded job table between calls: pass rebuild != 0 on the first call and

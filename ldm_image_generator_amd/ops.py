@@ -417,6 +417,12 @@ def uncast_bf16(x, out):
     return out
 
 
+def gconv3x3_bf16(x16, w16, bias, addend, out, B, H, W, C):
+    """Grouped 3x3 conv (32 per group) with bf16 operands: out = conv(x16) (+ bias) (+ addend), fp32 out (may alias addend)."""
+    _call("ldm_gconv3x3_bf16", _dev(x16, "x", BF16), _dev(w16, "w", BF16), _opt(bias, "bias"), _opt(addend, "addend"), _dev(out, "out"), B, H, W, C)
+    return out
+
+
 def film_hidden(p_rows, t_rows, out, B, HW, N):
     """out[b, pixel, :] = relu(P[pixel] + T[b]) -- Encodings.proj1 in separable form; ``out`` fp32 or bf16 [B*HW, N]."""
     bf = out.dtype == BF16

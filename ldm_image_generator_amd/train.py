@@ -452,11 +452,15 @@ def _uncast(x16):
     return out
 
 
+import os as _os
+_TN16_TARGET = int(_os.environ.get("LDM_TN16_TARGET", "512"))       # workgroups the split of the pixel reduction aims for (tuning knob)
+
+
 def tn16_splits(n_out, k_out, m_red):
     """Splits of the pixel reduction for ldm_gemm_tn_bf16: fill ~512 workgroups of 128 x 256 (K %% 256 == 0) or 128 x 128 tiles."""
     tiles = (n_out // 128) * (k_out // 256 if k_out % 256 == 0 else k_out // 128)
     s = 1
-    while tiles * s < 512 and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:
+    while tiles * s < _TN16_TARGET and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:
         s *= 2
     return s
 
@@ -494,9 +498,7 @@ def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
     xf16 = _e16(m, c, dev=dev)
     ops.channelnorm_film_bf16(rows, film, ctx.slot, xf, xf16, b, h * w, c, blk.norm.eps)
     y = torch.empty_like(rows)
-    ops.gemm(xf, m, 32, 288, [blk._conv_weight()], y, lda=c, ldw=288, biases=[blk.conv.bias.detach()], addend=rows, ldadd=c,
-             ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=32, groups=c // 32, a_gstride=32, w_gstride=32 * 288,
-             o_gstride=32, b_gstride=32)
+    ops.gconv3x3_bf16(xf16, ops.cast_bf16(blk._conv_weight()), blk.conv.bias.detach(), rows, y, b, h, w, c)
     sv = dict(blk=blk, x=rows, xf=xf, xf16=xf16, film=film, codes=codes16, enc_hidden=enc_hidden16, picks=picks, shape=shape)
     if blk.attention_flag:
         att = blk.self_attention.attention
@@ -563,8 +565,8 @@ def block_backward16(sv, dy, dy16, ctx, grads):
         dwi, dbi = grad_weight_rows16(dqkv16, xf16, m)
         grads.add(att.in_proj_weight, dwi)
         grads.add(att.in_proj_bias, ops.add_(dbi.clone(), dpad))
-    # ---- grouped 3x3 conv (fp32 kernels) ------------------------------------------------------------------
-    _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads)
+    # ---- grouped 3x3 conv: data gradient on the bf16 matrix cores, weight gradient by the fp32 kernel ----------
+    _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=dy16)
     # ---- ChannelNorm + FiLM, residual ---------------------------------------------------------------------
     film = sv["film"]
     dfilm16 = _e16(film.shape[0], film.shape[1], dev=dev)
@@ -575,16 +577,20 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     return dx, dx16
 
 
-def _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads):
-    """data gradient (accumulated into dxf) and weight / bias gradient of the grouped 3x3 conv (unet.py:30,44), fp32."""
+def _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=None):
+    """data gradient (accumulated into dxf) and weight / bias gradient of the grouped 3x3 conv (unet.py:30,44); the data
+    gradient takes bf16 operands when ``dy16`` (the bf16 shadow of dy) is given."""
     b, h, w = shape
     m, c = xf.shape
     dev = xf.device
     g = c // 32
     wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
     wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
-    ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
-             cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
+    if dy16 is not None:
+        ops.gconv3x3_bf16(dy16, ops.cast_bf16(wrot), None, dxf, dxf, b, h, w, c)
+    else:
+        ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
+                 cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
     dwconv = torch.empty(g, 32, 288, device=dev, dtype=torch.float32)
     sp = _gconv_splits(g, m) if 2 <= w <= 96 else 0
     if sp:
