@@ -453,7 +453,9 @@ def _uncast(x16):
 
 
 import os as _os
-_TN16_TARGET = int(_os.environ.get("LDM_TN16_TARGET", "512"))       # workgroups the split of the pixel reduction aims for (tuning knob)
+# workgroups the split of the pixel reduction aims for: one per CU -- more splits mean more fp32 partial planes to write and sum
+# (tiles x splits x tile bytes), which at C >= 512 costs as much as the GEMM itself (measured: 192-384 equal, 512 +2 %, 1024 +10 % step time)
+_TN16_TARGET = int(_os.environ.get("LDM_TN16_TARGET", "256"))
 
 
 def tn16_splits(n_out, k_out, m_red):
