@@ -309,6 +309,19 @@ int ldm_film_hidden_bwd_chunks(int B, int HW, int N);
 int ldm_film_hidden_bwd(const void *dh, const void *hid, int is_bf16, float *dP_part, float *dT_part, int B, int HW, int N, int zchunks,
                         void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * VectorQuantizer of the VAE training path (reference vae.py:7-26).
+ * ------------------------------------------------------------------------------------------------ */
+/* vae.py:18-22: idx[m] = argmax_n -cdist(x, emb)[m, n], FIRST maximum (torch.argmax), with torch.cdist's matrix-multiplication
+ * rounding (csrc/vq.hip).  x [M, D] fp32 rows, emb [N, D], idx [M] int64; D in {4, 8, 16}. */
+int ldm_vq_quantize_f32(const float *x, const float *emb, long long *idx, long long M, int N, int D, void *stream);
+int ldm_vq_embed_f32(const long long *idx, const float *emb, float *out, long long M, int D, void *stream);      /* vae.py:24-26 */
+/* vae.py:12-16: loss[0] = l1(x, e) + l1(e, x) over n = M*D elements; backward: dx = g sign(x - e) / n, demb[idx] += g sign(e - x) / n
+ * (demb [N, D] is zeroed by the call; gscale = 1-element device tensor with the incoming gradient) */
+int ldm_vq_loss_f32(const float *x, const float *e, long long n, float *loss, void *stream);
+int ldm_vq_loss_bwd_f32(const float *x, const float *e, const long long *idx, const float *gscale, float *dx, float *demb, long long M, int N, int D,
+                        void *stream);
+
 /* Grouped 3x3 conv of unet.py:30,44 (32 in / 32 out per group, zero pad 1) with bf16 operands, fp32 accumulate:
  * out[m, :] = conv(x)[m, :] (+ bias) (+ addend[m, :]);  x [B*H*W, C] bf16, w [C][9][32] bf16 (ldm_gemm_f32's packed grouped
  * layout: output channel, tap, input channel), bias [C] / addend [B*H*W, C] fp32 or NULL, out fp32 (may alias addend).

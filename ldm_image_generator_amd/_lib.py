@@ -138,6 +138,10 @@ SIGNATURES = {
     "ldm_channelnorm_film_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_channelnorm_film_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_gconv3x3_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_vq_quantize_f32": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "ldm_vq_embed_f32": (_I, [_P, _P, _P, _L, _I, _P]),
+    "ldm_vq_loss_f32": (_I, [_P, _P, _L, _P, _P]),
+    "ldm_vq_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "ldm_multi_cast_table_bytes": (ctypes.c_size_t, [_I]),
     "ldm_multi_cast_bf16": (_I, [ctypes.POINTER(CastJob), _I, _P, _I, ctypes.POINTER(_L), _P]),
     "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -417,6 +417,35 @@ def uncast_bf16(x, out):
     return out
 
 
+def vq_quantize(x_rows, emb):
+    """vae.py:18-22 on rows: x [M, D], emb [N, D] -> int64 indices [M] (first nearest codebook row, torch.cdist rounding)."""
+    m, d = x_rows.shape
+    idx = torch.empty(m, dtype=torch.int64, device=x_rows.device)
+    _call("ldm_vq_quantize_f32", _dev(x_rows, "x"), _dev(emb, "emb"), _dev(idx, "idx", torch.int64), m, emb.shape[0], d)
+    return idx
+
+
+def vq_embed(idx, emb):
+    out = torch.empty(idx.numel(), emb.shape[1], device=emb.device, dtype=torch.float32)
+    _call("ldm_vq_embed_f32", _dev(idx, "idx", torch.int64), _dev(emb, "emb"), _dev(out, "out"), idx.numel(), emb.shape[1])
+    return out
+
+
+def vq_loss(x_rows, e_rows):
+    loss = torch.empty(1, device=x_rows.device, dtype=torch.float32)
+    _call("ldm_vq_loss_f32", _dev(x_rows, "x"), _dev(e_rows, "e"), x_rows.numel(), _dev(loss, "loss"))
+    return loss
+
+
+def vq_loss_bwd(x_rows, e_rows, idx, gscale, n_emb):
+    m, d = x_rows.shape
+    dx = torch.empty_like(x_rows)
+    demb = torch.empty(n_emb, d, device=x_rows.device, dtype=torch.float32)
+    _call("ldm_vq_loss_bwd_f32", _dev(x_rows, "x"), _dev(e_rows, "e"), _dev(idx, "idx", torch.int64), _dev(gscale, "gscale"), _dev(dx, "dx"),
+          _dev(demb, "demb"), m, n_emb, d)
+    return dx, demb
+
+
 def gconv3x3_bf16(x16, w16, bias, addend, out, B, H, W, C):
     """Grouped 3x3 conv (32 per group) with bf16 operands: out = conv(x16) (+ bias) (+ addend), fp32 out (may alias addend)."""
     _call("ldm_gconv3x3_bf16", _dev(x16, "x", BF16), _dev(w16, "w", BF16), _opt(bias, "bias"), _opt(addend, "addend"), _dev(out, "out"), B, H, W, C)

@@ -7,8 +7,9 @@ dense 3x3 as implicit GEMM with fused bias + leaky_relu (+ residual),
 ConvTranspose2d(2,2) as one GEMM with a 2x2 scatter epilogue; ``to_rgb`` and the
 bilinear RGB accumulation are one fused HBM-bound kernel per stage.
 
-``Encoder`` (latent pre-encoding for train_ldm.py) reuses the same kernels.  ``VectorQuantizer``,
-``Discriminator`` and ``VAE.calclate_loss`` (VAE training) are outside the hot path and are not provided.
+``Encoder`` (latent pre-encoding for train_ldm.py) reuses the same kernels.  SURVEY 8f.4 (VAE training) is started
+with its integer part: ``VectorQuantizer`` (quantize with the reference's indices, embed, the two-sided L1 loss with gradients) and
+the forward of ``VAE.calclate_loss``; the ``Discriminator`` and the Encoder / Decoder backward are not provided.
 """
 import torch
 import torch.nn as nn
@@ -183,14 +184,76 @@ class Decoder(nn.Module):
         return rgb
 
 
+class _VQLossFunction(torch.autograd.Function):
+    """vae.py:12-16: l1(x, e.detach()) + l1(e, x.detach()) with e = embeddings[quantize(x)] -- two kernels each way."""
+
+    @staticmethod
+    def forward(fctx, x_rows, emb):
+        x_rows, emb = x_rows.contiguous().float(), emb.contiguous().float()
+        idx = ops.vq_quantize(x_rows, emb)
+        e_rows = ops.vq_embed(idx, emb)
+        fctx.save_for_backward(x_rows, e_rows, idx)
+        fctx.n_emb = emb.shape[0]
+        return ops.vq_loss(x_rows, e_rows).reshape(())
+
+    @staticmethod
+    def backward(fctx, gout):
+        x_rows, e_rows, idx = fctx.saved_tensors
+        dx, demb = ops.vq_loss_bwd(x_rows, e_rows, idx, gout.reshape(1).contiguous().float(), fctx.n_emb)
+        return dx, demb
+
+
+class VectorQuantizer(nn.Module):
+    """vae.py:7-26.  ``quantize`` returns the reference's indices: nearest codebook row under torch.cdist's own rounding, first
+    index on ties (ldm_vq_quantize_f32)."""
+
+    def __init__(self, num_embeddings=8192, dim=8):
+        super().__init__()
+        self.embeddings = nn.Parameter(torch.randn(num_embeddings, dim))
+
+    def _rows(self, x):
+        if x.shape[-1] != self.embeddings.shape[1]:
+            raise ValueError("last dimension of x must be the embedding dimension %d" % self.embeddings.shape[1])
+        return x.reshape(-1, x.shape[-1]).contiguous().float()
+
+    def calculate_loss(self, x):
+        return _VQLossFunction.apply(self._rows(x), self.embeddings)
+
+    @torch.no_grad()
+    def quantize(self, x):
+        return ops.vq_quantize(self._rows(x), self.embeddings.detach().contiguous()).reshape(x.shape[:-1])
+
+    def embed(self, x):
+        out = ops.vq_embed(x.reshape(-1).contiguous(), self.embeddings.detach().contiguous())
+        return out.reshape(tuple(x.shape) + (self.embeddings.shape[1],))
+
+
 class VAE(nn.Module):
-    """vae.py:30-52 restricted to the sampling path (decode)."""
+    """vae.py:30-52.  ``encode`` / ``decode`` are the sampling path; ``calclate_loss`` (sic) is the FORWARD of the VAE training
+    objective (the backward through Encoder / Decoder -- dense 3x3, ConvTranspose and bilinear gradients -- is not built, so the
+    call is only valid under ``torch.no_grad()``)."""
 
     def __init__(self, encoder, decoder, quantizer):
         super().__init__()
         self.encoder = encoder
         self.decoder = decoder
         self.quantizer = quantizer
+
+    def calclate_loss(self, x, noise_gain=0.1):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("VAE.calclate_loss: only the forward is implemented on the HIP path; call it under torch.no_grad()")
+        z = self.encoder(x)
+        noise = torch.randn(z.shape, device=x.device)
+        b = z.shape[0]
+        zn = torch.empty_like(z)                          # z * 1 + noise * gain, products and sum rounded like torch's two ops
+        ops.qsample(z, noise, torch.ones(b, device=x.device), torch.full((b,), float(noise_gain), device=x.device), zn)
+        z = zn
+        rows, _ = to_rows(z)                              # [B*h*w, 8] == z.reshape(B, C, -1).transpose(1, 2)
+        loss_reg = self.quantizer.calculate_loss(rows)
+        y = self.decoder(z)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        ops.l1_loss(x.contiguous().float(), y, loss)
+        return loss.reshape(()), loss_reg, y
 
     @torch.no_grad()
     def encode(self, x):

@@ -352,7 +352,49 @@ def encoder_cases():
     save("encoder_full", x=x, z=full(x))
 
 
+def vq_cases():
+    """VectorQuantizer (vae.py:7-26) on its default codebook size (8192 x 8): indices, embedding rows, the two-sided L1 loss and its
+    gradients, plus VAE.calclate_loss's forward on a tiny encoder / decoder with the noise replayed.  The codebook gets three
+    adversarial rows: two exact duplicates (the FIRST must win) and one row equal to a query (distance 0, the clamp path)."""
+    vq = ref_vae.VectorQuantizer()
+    emb = g("vq.emb", (8192, 8))
+    x = g("vq.x", (2, 1024, 8)) * 1.3
+    emb[5000] = emb[77]                                  # exact tie: index 77 wins wherever row 77 is nearest
+    x[0, 5] = emb[77] * 1.0001                           # ... and make it nearest for one query
+    x[1, 9] = emb[4242]                                  # distance exactly 0
+    with torch.no_grad():
+        vq.embeddings.copy_(emb)
+    xr = x.clone().requires_grad_()
+    idx = vq.quantize(xr)
+    loss = vq.calculate_loss(xr)
+    loss.backward()
+    arrs = dict(emb=emb, x=x, idx=idx, e_rows=vq.embed(idx).detach()[:, :16], loss=loss.detach(), dx=xr.grad,
+                demb_norm=vq.embeddings.grad.double().norm(), demb_rows=vq.embeddings.grad[[77, 4242, 5000, 0, 8191]],
+                demb_nonzero=(vq.embeddings.grad.abs().sum(1) > 0).sum())
+    # VAE.calclate_loss forward (vae.py:36-43) on a tiny encoder / decoder; the latent noise is replayed from the torch seed
+    enc = load_formula(ref_vae.Encoder(channels=[32, 64, 32], stages=[1, 2, 1]))
+    dec = load_formula(ref_vae.Decoder(channels=[64, 32, 32], stages=[1, 2, 1]))
+    vq2 = ref_vae.VectorQuantizer(num_embeddings=512, dim=8)
+    with torch.no_grad():
+        vq2.embeddings.copy_(g("vq2.emb", (512, 8)) * 0.2)
+    vae = ref_vae.VAE(enc, dec, vq2)
+    img = g("vae.x", (2, 3, 32, 32))
+    torch.manual_seed(11)
+    st = torch.get_rng_state()
+    with torch.no_grad():
+        z0 = enc(img)
+    noise = torch.randn(z0.shape)
+    torch.set_rng_state(st)
+    with torch.no_grad():
+        loss_recon, loss_reg, y = vae.calclate_loss(img, noise_gain=0.1)
+    arrs.update(vae_x=img, vae_noise=noise, vae_emb=vq2.embeddings.detach(), vae_loss_recon=loss_recon, vae_loss_reg=loss_reg, vae_y=y)
+    save("vq", **arrs)
+
+
 if __name__ == "__main__":
+    if "--vq-only" in sys.argv:
+        vq_cases()
+        sys.exit(0)
     if "--loss-full-only" in sys.argv:
         loss_full_cases()
         sys.exit(0)
@@ -368,3 +410,4 @@ if __name__ == "__main__":
     loss_full_cases()
     vae_cases()
     encoder_cases()
+    vq_cases()
