@@ -60,7 +60,7 @@ class DDPM(nn.Module):
 
     @torch.no_grad()
     def sample(self, x_shape=(1, 3, 64, 64), condition=None, seed=None, num_steps=20, use_autocast=True, schedule='linear',
-               eta=0, x_init=None, progress=True):
+               eta=0, x_init=None, progress=True, shard=None):
         device = next(self.model.parameters()).device
         if seed is not None:
             random.seed(seed)
@@ -88,6 +88,12 @@ class DDPM(nn.Module):
                     self.model._uniform_time = (t, t_dev[k:k + 1])
                 e_theta = self.model(x=x, time=t_tensor, condition=None)
                 e = torch.randn(*x_shape, device=device)
+                if shard is not None and eta != 0:
+                    # data-parallel sampling with eta > 0: the per-step noise of the GLOBAL batch comes from one CPU generator and
+                    # every rank takes its slice (as for x_T), so sharded == unsharded and ranks never share noise
+                    gb, lo, hi = shard
+                    gen = torch.Generator().manual_seed((0 if seed is None else int(seed)) * 1000003 + i + 1)
+                    e = torch.randn(gb, *x_shape[1:], generator=gen)[lo:hi].to(device)
                 sigma = eta * torch.sqrt((1 - alpha[t_next]) / (1 - alpha[t])) * torch.sqrt(1 - alpha[t] / alpha[t_next])
                 s1 = torch.sqrt(1 - alpha[t])
                 s2 = torch.sqrt(alpha[t])

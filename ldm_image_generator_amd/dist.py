@@ -96,7 +96,9 @@ def allreduce_gradients(params, world):
     used = [p for p in params if p.grad is not None]
     if world == 1 or not used:
         return len(used)
-    flat = torch.cat([p.grad.reshape(-1) for p in used])            # one bucket: 288 GB of HBM, point-to-point xGMI
+    # ONE bucket (<= 1.5 GB of fp32 gradients): xGMI is point-to-point, so one large ring all-reduce beats many small ones; the
+    # copy into / out of the flat buffer is 2 x 1.5 GB of HBM traffic (< 1 ms).  Not overlapped with the backward.
+    flat = torch.cat([p.grad.reshape(-1) for p in used])
     dist.all_reduce(flat, op=dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM)
     if not flat.is_cuda:
         flat /= world                                                # gloo (CPU tests) has no AVG
@@ -112,6 +114,10 @@ def train_step(ddpm, optimizer, x_local, step_seed, world):
     """One optimisation step of train_ldm.py:76-86 on this rank's shard of the global batch."""
     import random
     random.seed(step_seed)                                           # identical expert / depth decisions on all ranks
+    # ... but DIFFERENT timesteps and noise per rank (ddpm.py:40,44 draw them from torch's generators): a caller that seeds torch
+    # identically on every rank would otherwise train all shards on the same (t, e)
+    rank = dist.get_rank() if (world > 1 and dist.is_initialized()) else 0
+    torch.manual_seed(step_seed * world + rank)
     optimizer.zero_grad()
     loss = ddpm.calculate_loss(x_local)
     loss.backward()

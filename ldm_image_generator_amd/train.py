@@ -737,8 +737,14 @@ class UNetFunction(torch.autograd.Function):
         ops.stem_bwd(x, drows, dw0, b, cin, h * w, c0)
         grads.add(net.encoder_first.weight, dw0)
         grads.add(net.encoder_first.bias, ops.colsum(drows, b * h * w, c0))
+        dx = None
+        if fctx.needs_input_grad[1]:
+            # dL/dx of the 1x1 stem (a trainable encoder upstream, gradient-based guidance): drows . W, rows -> NCHW -- the
+            # head kernel's arithmetic with the stem weight [C0, Cin]
+            dx = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
+            ops.head_nchw(drows, _w2d(net.encoder_first.weight).contiguous(), None, dx, b, c0, h * w, cin)
         fctx.tape = None
-        return (None, None, None) + tuple(grads.g.get(p) for p in params)
+        return (None, dx, None) + tuple(grads.g.get(p) for p in params)
 
 
 class L1LossFunction(torch.autograd.Function):

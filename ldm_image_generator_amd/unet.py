@@ -26,6 +26,17 @@ from .modules import ChannelNorm, RandomMoE, from_rows, to_rows, w2d
 from .sinusoidal import PositionalEncoding2d, TimeEncoding2d
 
 
+# bumped on every nn.Module.register_parameter in the process: a cheap "some Parameter object may have been replaced" signal
+_PARAM_GENERATION = [0]
+
+
+def _bump_param_generation(module, name, param):
+    _PARAM_GENERATION[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_param_generation)
+
+
 class TimeContext:
     """Per-forward bookkeeping: distinct timesteps, sample->slot map, and the
     sin/cos code table of every (C, H, W) seen so far (shared by all blocks of a level)."""
@@ -250,17 +261,27 @@ class UNet(nn.Module):
         # The plan holds POINTERS to the live parameters, so in-place updates (optimizer steps, load_state_dict)
         # need no rebuild; only the re-laid-out grouped-conv weights are copies (checked by version here), and
         # device / dtype moves drop the plan in _apply().
-        order = self._plan[3] if self._plan is not None else \
-            [blk for l in self.encoder_stages for blk in l.stage.blocks] + [blk for l in self.decoder_stages for blk in l.stage.blocks]
-        key = (str(dev), tuple((blk.conv.weight.data_ptr(), blk.conv.weight._version) for blk in order))
-        if self._plan is not None and self._plan[0] == key:
-            return self._plan[1]
-        keep = []
+        # Staleness (three ways a weight can change under the plan): (1) a Parameter OBJECT is replaced (module.weight = ...,
+        # load_state_dict(assign=True)): every registration bumps the process-wide _PARAM_GENERATION; (2) a parameter's storage is
+        # swapped (p.data = new): the data_ptr of every captured source tensor is part of the key; (3) the packed grouped-conv
+        # copies: keyed on the conv weight's version.  In-place writes through ``.data`` (p.data.copy_()) bump no version and are
+        # invisible to (3): call invalidate_caches() after such a write.
+        if self._plan is not None:
+            order, captured = self._plan[3], self._plan[4]
+            key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured),
+                   tuple(blk.conv.weight._version for blk in order))
+            if self._plan[0] == key:
+                return self._plan[1]
+        order = [blk for l in self.encoder_stages for blk in l.stage.blocks] + [blk for l in self.decoder_stages for blk in l.stage.blocks]
+        keep, captured = [], []
 
         def ptr(t):
+            src = t
             t = t.detach()
             if not t.is_contiguous():
                 t = t.contiguous()
+            elif isinstance(src, nn.Parameter):
+                captured.append(src)                 # the plan points INTO this parameter's storage
             keep.append(t)
             return t.data_ptr()
 
@@ -298,8 +319,19 @@ class UNet(nn.Module):
         plan.head_w, plan.head_b = ptr(self.decoder_last.weight), ptr(self.decoder_last.bias)
         plan.blocks = ctypes.cast(blocks, ctypes.POINTER(UNetBlockDesc))
         keep.append(blocks)
-        self._plan = (key, plan, keep, order)
+        key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured), tuple(blk.conv.weight._version for blk in order))
+        self._plan = (key, plan, keep, order, captured)
         return plan
+
+    def invalidate_caches(self):
+        """Drop every derived copy of the weights (native plan, pointer tables, packed grouped-conv filters).  Needed only after
+        writing weights in place through ``.data`` (p.data.copy_(), EMA swaps, clipping), which bumps no version counter; updates
+        through the Parameter itself (optimizer steps, load_state_dict, p.copy_ under no_grad) are tracked automatically."""
+        self._plan = None
+        self._tables = {}
+        for stack in list(self.encoder_stages) + list(self.decoder_stages):
+            for blk in stack.stage.blocks:
+                blk._packed = None
 
     def _apply(self, fn, *args, **kwargs):
         self._plan = None                  # parameters are about to be replaced (.to / .cuda / .float)
@@ -334,8 +366,10 @@ class UNet(nn.Module):
         return out
 
     def forward(self, x, time, condition=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training step: same kernels + saved activations, hand-written backward (train.py)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training step: same kernels + saved activations, hand-written backward (train.py).  Like the reference's autograd this
+            # keeps every block's activations alive (~21 C floats per pixel and block: 63 GB fp32 / 43 GB bf16 at the cfg-5 shape)
+            # whether or not the module is in train() mode -- wrap pure inference in torch.no_grad(), as ddpm.sample does.
             from .train import UNetFunction
             params = [p for p in self.parameters() if p.requires_grad]
             return UNetFunction.apply(self, x, time, *params)
