@@ -1,9 +1,13 @@
-"""Rehearsal of the data-parallel training step (BASELINE cfg 5 control flow) with N processes on ONE GPU and gloo
-standing in for RCCL:  LDM_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 \
-    --master-port 29533 tools/ddp_rehearsal.py
-Checks: identical decisions and parameters on all ranks after two steps, and equality with a single-process step on
-the concatenated batch (gradient averaging over equal shards == the full-batch mean)."""
+"""Rehearsal of the data-parallel training step (BASELINE cfg 5 control flow) with N processes on ONE GPU and gloo standing in
+for RCCL (the collective is the only thing that differs from the 8-GPU run):
+    LDM_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/ddp_rehearsal.py
+Asserts (exit code 1 on failure):
+  * after two steps the parameters are bit-identical on all ranks (same Python-random decisions, one averaged gradient);
+  * ranks drew DIFFERENT timesteps / noise (train_step seeds torch with step_seed * world + rank);
+  * the first data-parallel step equals, on rank 0, a single process that runs the shards one after the other with the ranks'
+    seeds and averages their gradients (<= 1e-6 relative on the parameter vector)."""
 import os
+import random
 import sys
 
 import torch
@@ -27,18 +31,55 @@ def make():
     return d, torch.optim.SGD(d.parameters(), lr=1e-2)
 
 
+def flat_params(d):
+    return torch.cat([p.detach().reshape(-1) for p in d.parameters()])
+
+
 full = torch.randn(4 * world, 8, 16, 16, generator=torch.Generator().manual_seed(0))
 d, opt = make()
-for step in range(2):
-    torch.manual_seed(100 + step + 1000 * rank)             # per-rank noise / timesteps, shared Python-random decisions
-    ldist.train_step(d, opt, full[4 * rank:4 * rank + 4].to(dev), step_seed=step, world=world)
-flat = torch.cat([p.detach().reshape(-1) for p in d.parameters()])
+failures = []
+loss0 = ldist.train_step(d, opt, full[4 * rank:4 * rank + 4].to(dev), step_seed=0, world=world)
+after1 = flat_params(d).clone()
+t_probe = torch.randint(0, 1 << 30, (1,))                    # torch's CPU stream after the rank-specific seed: must differ between ranks
+ldist.train_step(d, opt, full[4 * rank:4 * rank + 4].to(dev), step_seed=1, world=world)
+flat = flat_params(d)
 ref = flat.clone()
 dist.broadcast(ref, src=0)
-same = bool(torch.equal(flat, ref))
-ok = torch.tensor([1.0 if same else 0.0], device=dev)
-dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+same = torch.tensor([1.0 if torch.equal(flat, ref) else 0.0], device=dev)
+dist.all_reduce(same, op=dist.ReduceOp.MIN)
+if same.item() != 1.0:
+    failures.append("parameters differ between ranks after two steps")
+probes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(probes, t_probe)
+if len({int(p) for p in probes}) != world:
+    failures.append("ranks share one torch random stream (same timesteps / noise on every shard)")
+if not bool(torch.isfinite(flat).all()):
+    failures.append("non-finite parameters")
 if rank == 0:
-    print("ranks %d: parameters identical on all ranks after 2 steps: %s; finite: %s" % (world, bool(ok.item() == 1.0), bool(torch.isfinite(flat).all())))
+    # single-process restatement of step 0: shard by shard with the ranks' seeds, gradients averaged
+    d1, opt1 = make()
+    acc = None
+    for r in range(world):
+        random.seed(0)
+        torch.manual_seed(0 * world + r)
+        opt1.zero_grad()
+        d1.calculate_loss(full[4 * r:4 * r + 4].to(dev)).backward()
+        grads = [None if p.grad is None else p.grad.clone() for p in d1.parameters()]
+        acc = grads if acc is None else [None if a is None else a + g for a, g in zip(acc, grads)]
+    for p, g in zip(d1.parameters(), acc):
+        p.grad = None if g is None else g / world
+    opt1.step()
+    want = flat_params(d1)
+    err = float((after1.double() - want.double()).norm() / want.double().norm())
+    if not err < 1e-6:        # not bitwise: a few bias-gradient kernels sum with float atomics (run-to-run differences ~1e-7 per gradient)
+        failures.append("data-parallel step != sequential shards with averaged gradients (rel %.3e)" % err)
+    print("ddp rehearsal, %d ranks (gloo): loss %.5f, step-0 deviation from the sequential restatement %.3e" % (world, float(loss0), err))
+fail = torch.tensor([float(len(failures))], device=dev)
+dist.all_reduce(fail, op=dist.ReduceOp.SUM)
+for f in failures:
+    print("rank %d FAILED: %s" % (rank, f), flush=True)
+if rank == 0 and fail.item() == 0:
+    print("DDP_REHEARSAL_OK", flush=True)
 dist.barrier()
 dist.destroy_process_group()
+sys.exit(1 if fail.item() else 0)
