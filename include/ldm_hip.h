@@ -280,6 +280,12 @@ int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, co
  * the a/w group strides count bf16 elements (K, N multiples of 64; rows 16-byte addressable).  bias / addend are fp32.
  * out_bf16 == 0: d->out is fp32 [M, ldo];  != 0: d->out is bf16 [M, ldo] (no addend).  Rows in / rows out only, no gate. */
 int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream);
+/* ReGLU forward in one launch (modules.py:14-15): d->act == LDM_ACT_GATE, d->w / d->w2 (+ bias / bias2) the "a" / "b" branches,
+ * d->out = a * relu(b) as bf16 [M, ldo]; a_pre / b_pre (both or neither): bf16 [M, ldo] copies of the pre-activations a, b that
+ * the backward needs.  ldm_gemm_bf16_gate_bwd is the data-gradient GEMM dh = dy . Wc (d as for ldm_gemm_bf16) with the gate's
+ * backward in its epilogue: d->out = da = dh * relu(b), db = dh * a * (b > 0) (all bf16 [M, ldo]); dh itself is never stored. */
+int ldm_gemm_bf16_gate_fwd(const ldm_gemm_desc *d, void *a_pre, void *b_pre, void *stream);
+int ldm_gemm_bf16_gate_bwd(const ldm_gemm_desc *d, const void *a_pre, const void *b_pre, void *db, void *stream);
 /* weight gradient from bf16 operands as they lie in memory (ldm_gemm_tn_f32's contract; M / splits a multiple of 64):
  * out[s][n][k] fp32 = sum over the rows m of split s of a[m*lda + n] * b[m*ldb + k]; colsum_a optional [splits][N] fp32. */
 int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, long long ldb, float *out, float *colsum_a, int M, int N, int K, int splits,

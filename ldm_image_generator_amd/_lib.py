@@ -128,6 +128,8 @@ SIGNATURES = {
     "ldm_window_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     # bf16 training step
     "ldm_gemm_bf16": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
+    "ldm_gemm_bf16_gate_fwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P]),
+    "ldm_gemm_bf16_gate_bwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P, _P]),
     "ldm_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_cast_bf16": (_I, [_P, _P, _L, _P]),
     "ldm_uncast_bf16": (_I, [_P, _P, _L, _P]),

@@ -9,28 +9,40 @@
 
 using namespace ldmgemm;
 
-int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st);
+int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate);
 
-extern "C" int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream)
+namespace {
+
+// mode 0: plain;  1: gate forward (d->w2 / bias2 = the "b" branch; x1 = a_pre out, x2 = b_pre out, both optional together);
+// 2: gate backward fused behind the GEMM that produces dh (x1 = a_pre in, x2 = b_pre in, x3 = db out; d->out = da)
+int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mode, void *x1, void *x2, void *x3, void *stream)
 {
-    LDM_REQUIRE(d != nullptr && d->a && d->out, "ldm_gemm_bf16: null descriptor / operand");
-    LDM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->N % 64 == 0 && d->K % 64 == 0, "ldm_gemm_bf16: M=%d, N=%d and K=%d must be positive multiples of (1, 64, 64)",
+    LDM_REQUIRE(d != nullptr && d->a && d->out, "%s: null descriptor / operand", who);
+    LDM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->N % 64 == 0 && d->K % 64 == 0, "%s: M=%d, N=%d and K=%d must be positive multiples of (1, 64, 64)", who,
                 d->M, d->N, d->K);
-    LDM_REQUIRE(d->a_mode == LDM_A_ROWS && d->o_mode == LDM_O_ROWS && d->act != LDM_ACT_GATE && !d->w_table,
-                "ldm_gemm_bf16: rows in / rows out, no gate, no pointer table");
-    LDM_REQUIRE(d->nseg >= 1 && d->nseg <= LDM_MAX_SEG && (d->seg_mode == LDM_SEG_N || d->seg_mode == LDM_SEG_K), "ldm_gemm_bf16: nseg=%d seg_mode=%d", d->nseg,
+    LDM_REQUIRE(d->a_mode == LDM_A_ROWS && d->o_mode == LDM_O_ROWS && !d->w_table, "%s: rows in / rows out, no pointer table", who);
+    LDM_REQUIRE((d->act == LDM_ACT_GATE) == (mode == 1), "%s: act=%d does not fit this entry point", who, d->act);
+    LDM_REQUIRE(d->nseg >= 1 && d->nseg <= LDM_MAX_SEG && (d->seg_mode == LDM_SEG_N || d->seg_mode == LDM_SEG_K), "%s: nseg=%d seg_mode=%d", who, d->nseg,
                 d->seg_mode);
-    LDM_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && ldm_aligned16(d->a), "ldm_gemm_bf16: rows of A and W must be 16-byte addressable (lda, ldw multiples of 8)");
+    LDM_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && ldm_aligned16(d->a), "%s: rows of A and W must be 16-byte addressable (lda, ldw multiples of 8)", who);
     const int groups = d->groups > 0 ? d->groups : 1;
-    LDM_REQUIRE(d->a_gstride % 8 == 0 && d->w_gstride % 8 == 0, "ldm_gemm_bf16: group strides must be multiples of 8 elements");
+    LDM_REQUIRE(d->a_gstride % 8 == 0 && d->w_gstride % 8 == 0, "%s: group strides must be multiples of 8 elements", who);
     const int seg_total = d->seg_mode == LDM_SEG_N ? d->N : d->K;
     const int seg_len = d->nseg == 1 ? seg_total : d->seg_len;
-    LDM_REQUIRE(seg_len > 0 && seg_len % 64 == 0 && (long long)seg_len * d->nseg == seg_total, "ldm_gemm_bf16: segments (%d x %d) do not cover %d", d->nseg,
-                seg_len, seg_total);
-    for (int s = 0; s < d->nseg; ++s) LDM_REQUIRE(d->w[s] && ldm_aligned16(d->w[s]), "ldm_gemm_bf16: weight segment %d null/unaligned", s);
-    LDM_REQUIRE(!(out_bf16 && d->addend), "ldm_gemm_bf16: an addend needs the fp32 output");
-    if (out_bf16)
-        LDM_REQUIRE((((size_t)d->out) & 7) == 0 && d->ldo % 4 == 0 && d->o_gstride % 4 == 0, "ldm_gemm_bf16: bf16 output must be 8-byte addressable");
+    LDM_REQUIRE(seg_len > 0 && seg_len % 64 == 0 && (long long)seg_len * d->nseg == seg_total, "%s: segments (%d x %d) do not cover %d", who, d->nseg, seg_len,
+                seg_total);
+    LDM_REQUIRE(!(mode == 1 && d->seg_mode == LDM_SEG_K && d->nseg > 1), "%s: GATE with K-segments is not supported", who);
+    for (int s = 0; s < d->nseg; ++s) {
+        LDM_REQUIRE(d->w[s] && ldm_aligned16(d->w[s]), "%s: weight segment %d null/unaligned", who, s);
+        if (mode == 1) LDM_REQUIRE(d->w2[s] && ldm_aligned16(d->w2[s]), "%s: gate weight segment %d null/unaligned", who, s);
+    }
+    LDM_REQUIRE(!(out_bf16 && d->addend), "%s: an addend needs the fp32 output", who);
+    if (out_bf16) LDM_REQUIRE((((size_t)d->out) & 7) == 0 && d->ldo % 4 == 0 && d->o_gstride % 4 == 0, "%s: bf16 output must be 8-byte addressable", who);
+    if (mode) {
+        LDM_REQUIRE(out_bf16 && groups == 1, "%s: the fused gate forms write bf16 and take one group", who);
+        LDM_REQUIRE((x1 == nullptr) == (x2 == nullptr) && (mode == 1 || (x1 && x3)), "%s: missing pre-activation / output buffer", who);
+        LDM_REQUIRE((((size_t)x1 | (size_t)x2 | (size_t)x3) & 7) == 0, "%s: bf16 side buffers must be 8-byte addressable", who);
+    }
     GemmP p{};
     p.a = d->a; p.lda = d->lda / 2; p.M = d->M; p.N = d->N; p.K = d->K / 2;          // K axis in 4-byte units from here on
     p.cpt = 1;
@@ -39,6 +51,8 @@ extern "C" int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream)
     for (int s = 0; s < LDM_MAX_SEG; ++s) {
         p.w[s] = s < d->nseg ? d->w[s] : nullptr;
         p.bias[s] = s < d->nseg ? d->bias[s] : nullptr;
+        p.w2[s] = (mode == 1 && s < d->nseg) ? d->w2[s] : nullptr;
+        p.bias2[s] = (mode == 1 && s < d->nseg) ? d->bias2[s] : nullptr;
     }
     p.ldw = d->ldw / 2; p.act = d->act; p.slope = d->slope;
     p.addend = d->addend; p.ldadd = d->ldadd; p.out = d->out; p.ldo = d->ldo;
@@ -46,16 +60,36 @@ extern "C" int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream)
     p.a_gstride = d->a_gstride / 2; p.w_gstride = d->w_gstride / 2; p.o_gstride = d->o_gstride; p.b_gstride = d->b_gstride;
     p.wide_ok = out_bf16 ? 1
                          : (ldm_aligned16(d->out) && d->ldo % 4 == 0 && d->o_gstride % 4 == 0 && (!d->addend || (ldm_aligned16(d->addend) && d->ldadd % 4 == 0)));
+    if (mode == 1) { p.out2 = x1; p.out3 = x2; }
+    if (mode == 2) { p.in2 = x1; p.in3 = x2; p.out2 = x3; }
     hipStream_t st = (hipStream_t)stream;
     const double mn = (double)d->M * d->N * groups;
-    void *rec = ldm_prof_begin(LDM_PROF_GEMM_BF16, 2.0 * mn * d->K, st,
-                               2.0 * ((double)d->M * d->K * (d->a_gstride || groups == 1 ? groups : 1) + (double)d->N * d->K * groups) +
-                                   mn * (out_bf16 ? 2.0 : 4.0) + (d->addend ? mn * 4.0 : 0.0));
-    const int ok = ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st);
+    const double out_planes = mode == 1 ? (x1 ? 3.0 : 1.0) : (mode == 2 ? 2.0 : 1.0);
+    void *rec = ldm_prof_begin(LDM_PROF_GEMM_BF16, 2.0 * mn * d->K * (mode == 1 ? 2.0 : 1.0), st,
+                               2.0 * ((double)d->M * d->K * (d->a_gstride || groups == 1 ? groups : 1) + (double)d->N * d->K * groups * (mode == 1 ? 2.0 : 1.0)) +
+                                   mn * (out_bf16 ? 2.0 : 4.0) * out_planes + (mode == 2 ? mn * 4.0 : 0.0) + (d->addend ? mn * 4.0 : 0.0));
+    const int ok = ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st, mode == 1);
     ldm_prof_end(rec, st);
-    LDM_REQUIRE(ok, "ldm_gemm_bf16: no kernel instance for this shape (N=%d, seg_len=%d)", d->N, seg_len);
-    LDM_CHECK_LAUNCH("ldm_gemm_bf16");
+    LDM_REQUIRE(ok, "%s: no kernel instance for this shape (N=%d, seg_len=%d)", who, d->N, seg_len);
+    LDM_CHECK_LAUNCH(who);
     return LDM_OK;
+}
+
+}  // namespace
+
+extern "C" int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream)
+{
+    return gemm_bf16_impl("ldm_gemm_bf16", d, out_bf16, 0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ldm_gemm_bf16_gate_fwd(const ldm_gemm_desc *d, void *a_pre, void *b_pre, void *stream)
+{
+    return gemm_bf16_impl("ldm_gemm_bf16_gate_fwd", d, 1, 1, a_pre, b_pre, nullptr, stream);
+}
+
+extern "C" int ldm_gemm_bf16_gate_bwd(const ldm_gemm_desc *d, const void *a_pre, const void *b_pre, void *db, void *stream)
+{
+    return gemm_bf16_impl("ldm_gemm_bf16_gate_bwd", d, 1, 2, (void *)a_pre, (void *)b_pre, db, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

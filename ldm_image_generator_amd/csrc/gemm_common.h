@@ -28,6 +28,11 @@ struct GemmP {
     int wide_ok;                                // rows output (and addend) 16-byte addressable: the stream kernel may use its wide epilogue
     const float *wtab[LDM_MAX_TABLE];
     const float *btab[LDM_MAX_TABLE];
+    // bf16 training fusions of the wide epilogue (ldm_gemm_bf16_gate_fwd / _bwd), all bf16 [M, ldo] like `out`:
+    //   gate forward : out = a * relu(b) AND out2 = a, out3 = b (the pre-activations the backward needs)
+    //   gate backward: the GEMM result is dh; in2 = a, in3 = b;  out = dh * relu(b),  out2 = dh * a * (b > 0)
+    void *out2, *out3;
+    const void *in2, *in3;
 };
 
 // 64 B of zeros (one copy per translation unit): target of "absent operand" loads, so that optional
@@ -332,42 +337,75 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
     unsigned short *obase16 = (unsigned short *)p.out + oelem;
     float *wr = scratch + wl.wr_off;
     const float *rd = scratch + wl.rd_off;
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    // passes over the tile: 1, or 3 for the gate forward that also saves its pre-activations (hid, a, b)
+    const int npass = (GATE && OBF && p.out2 != nullptr) ? 3 : 1;
+    const bool gate_bwd = !GATE && OBF && p.in2 != nullptr;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        unsigned short *ob16 = pass == 0 ? obase16 : (unsigned short *)(pass == 1 ? p.out2 : p.out3) + oelem;
 #pragma unroll
-    for (int im = 0; im < TM; ++im) {
+        for (int im = 0; im < TM; ++im) {
+            u32x2_t ga[4 * TN], gb[4 * TN];                 // gate backward: the saved pre-activations of this lane's row pieces
+            if (gate_bwd) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                float v = acc[0][im][jn][e] + b1[jn];
-                if (GATE) {
-                    const float gt = acc[NACC - 1][im][jn][e] + c.b2[jn];
-                    v = v * fmaxf(gt, 0.f);
-                } else if (ACT == LDM_ACT_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (ACT == LDM_ACT_LRELU) {
-                    v = v > 0.f ? v : v * p.slope;
+                for (int k = 0; k < 4 * TN; ++k) {
+                    int roff = im * 32 + k * RPI;
+                    if (!full && row0 + roff >= p.M) roff = p.M - 1 - row0;          // clamp (the result is not stored)
+                    ga[k] = *(const u32x2_t *)((const unsigned short *)p.in2 + oelem + (long long)roff * ldo_);
+                    gb[k] = *(const u32x2_t *)((const unsigned short *)p.in3 + oelem + (long long)roff * ldo_);
                 }
-                // local row (e & 3) + 8 (e >> 2) + 4 h  ->  slot (bits 0, 2 swapped) = h | (e & 2) | (e & 1) << 2 | 8 (e >> 2)
-                int off;
-                if (TN == 1) off = (e >> 2) * 1024 + ((e & 2) | ((e & 1) << 2)) * 32;
-                else off = (2 * (e >> 2) + (e & 1)) * 1024 + (e & 2) * 64 + jn * 32;
-                wr[off] = v;
             }
 #pragma unroll
-        for (int k = 0; k < 4 * TN; ++k) {
-            const int off = (TN == 1) ? k * 1024 : (k >> 1) * 2048 + (k & 1) * 64;
-            f32x4 v = *(const f32x4 *)(rd + off);
-            if (use_pre) {
+            for (int e = 0; e < 16; ++e)
 #pragma unroll
-                for (int cix = 0; cix < 4; ++cix) v[cix] += pre[im][(4 * k + cix) >> 4][(4 * k + cix) & 15];
-            }
-            const int roff = im * 32 + k * RPI;
-            if (full || row0 + roff < p.M) {
-                if constexpr (OBF) {
-                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                    *(u32x2_t *)(obase16 + roff * ldo_) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                } else {
-                    *(f32x4 *)(obase + roff * ldo_) = v;
+                for (int jn = 0; jn < TN; ++jn) {
+                    float v = acc[0][im][jn][e] + b1[jn];
+                    if (GATE) {
+                        const float gt = acc[NACC - 1][im][jn][e] + c.b2[jn];
+                        if (pass == 0) v = v * fmaxf(gt, 0.f);
+                        else if (pass == 2) v = gt;
+                    } else if (ACT == LDM_ACT_RELU) {
+                        v = fmaxf(v, 0.f);
+                    } else if (ACT == LDM_ACT_LRELU) {
+                        v = v > 0.f ? v : v * p.slope;
+                    }
+                    // local row (e & 3) + 8 (e >> 2) + 4 h  ->  slot (bits 0, 2 swapped) = h | (e & 2) | (e & 1) << 2 | 8 (e >> 2)
+                    int off;
+                    if (TN == 1) off = (e >> 2) * 1024 + ((e & 2) | ((e & 1) << 2)) * 32;
+                    else off = (2 * (e >> 2) + (e & 1)) * 1024 + (e & 2) * 64 + jn * 32;
+                    wr[off] = v;
+                }
+#pragma unroll
+            for (int k = 0; k < 4 * TN; ++k) {
+                const int off = (TN == 1) ? k * 1024 : (k >> 1) * 2048 + (k & 1) * 64;
+                f32x4 v = *(const f32x4 *)(rd + off);
+                if (use_pre) {
+#pragma unroll
+                    for (int cix = 0; cix < 4; ++cix) v[cix] += pre[im][(4 * k + cix) >> 4][(4 * k + cix) & 15];
+                }
+                const int roff = im * 32 + k * RPI;
+                if (full || row0 + roff < p.M) {
+                    if constexpr (OBF) {
+                        if (gate_bwd) {
+                            float da[4], db[4];
+#pragma unroll
+                            for (int cix = 0; cix < 4; ++cix) {
+                                const unsigned wa = ga[k][cix >> 1], wb = gb[k][cix >> 1];
+                                const float av = __uint_as_float((cix & 1) ? (wa & 0xFFFF0000u) : (wa << 16));
+                                const float bv = __uint_as_float((cix & 1) ? (wb & 0xFFFF0000u) : (wb << 16));
+                                da[cix] = v[cix] * fmaxf(bv, 0.f);
+                                db[cix] = bv > 0.f ? v[cix] * av : 0.f;
+                            }
+                            *(u32x2_t *)(ob16 + roff * ldo_) = u32x2_t{pack_bf16x2(da[0], da[1]), pack_bf16x2(da[2], da[3])};
+                            *(u32x2_t *)((unsigned short *)p.out2 + oelem + (long long)roff * ldo_) =
+                                u32x2_t{pack_bf16x2(db[0], db[1]), pack_bf16x2(db[2], db[3])};
+                        } else {
+                            *(u32x2_t *)(ob16 + roff * ldo_) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        }
+                    } else {
+                        *(f32x4 *)(obase + roff * ldo_) = v;
+                    }
                 }
             }
         }

@@ -365,6 +365,50 @@ def gemm_bf16(a, M, N, K, weights, out, *, lda=None, ldo=None, biases=None, ldw=
     return out
 
 
+def _desc_bf16(a, M, N, K, weights, out, biases, seg_mode, act=ACT_NONE, weights2=None, biases2=None):
+    d = GemmDesc()
+    d.a = _dev(a, "a", BF16)
+    d.lda = K
+    d.M, d.N, d.K = M, N, K
+    d.a_mode = A_ROWS
+    nseg = len(weights)
+    d.nseg, d.seg_mode = nseg, seg_mode
+    d.seg_len = (N if seg_mode == SEG_N else K) // nseg
+    for s in range(nseg):
+        d.w[s] = _dev(weights[s], "weight", BF16)
+        if biases is not None and biases[s] is not None:
+            d.bias[s] = _dev(biases[s], "bias")
+        if weights2 is not None:
+            d.w2[s] = _dev(weights2[s], "weight2", BF16)
+            if biases2 is not None and biases2[s] is not None:
+                d.bias2[s] = _dev(biases2[s], "bias2")
+    d.ldw = K if seg_mode == SEG_N else K // nseg
+    d.act = act
+    d.out = _dev(out, "out", BF16)
+    d.ldo = d.ldadd = N
+    d.o_mode = O_ROWS
+    d.groups = 1
+    return d
+
+
+def gemm_bf16_gate_fwd(a, M, N, K, weights_a, weights_b, hid, *, biases_a=None, biases_b=None, a_pre=None, b_pre=None):
+    """ReGLU forward in one launch: hid = (A Wa^T + ba) * relu(A Wb^T + bb), all bf16; a_pre / b_pre (optional, both) receive the
+    pre-activations.  Weight segments along N select experts by pointer."""
+    d = _desc_bf16(a, M, N, K, weights_a, hid, biases_a, SEG_N, ACT_GATE, weights_b, biases_b)
+    _lib.check(_lib.load().ldm_gemm_bf16_gate_fwd(ctypes.byref(d), _opt(a_pre, "a_pre", BF16), _opt(b_pre, "b_pre", BF16), _stream()),
+               "ldm_gemm_bf16_gate_fwd")
+    return hid
+
+
+def gemm_bf16_gate_bwd(dy, M, N, K, weights_t, a_pre, b_pre, da, db):
+    """dh = dy . Wc (weights_t: the transposed c-weights, N-segments) with the gate's backward in the epilogue:
+    da = dh * relu(b), db = dh * a * (b > 0); everything bf16 [M, N]."""
+    d = _desc_bf16(dy, M, N, K, weights_t, da, None, SEG_N)
+    _lib.check(_lib.load().ldm_gemm_bf16_gate_bwd(ctypes.byref(d), _dev(a_pre, "a_pre", BF16), _dev(b_pre, "b_pre", BF16), _dev(db, "db", BF16),
+                                                  _stream()), "ldm_gemm_bf16_gate_bwd")
+    return da, db
+
+
 def gemm_tn_bf16(a, b, out, M, N, K, splits=1, lda=None, ldb=None, colsum=None):
     """out[s] [N, K] fp32 = sum over the rows of split s of a[m, :N]^T b[m, :K], bf16 operands as they lie in memory."""
     _call("ldm_gemm_tn_bf16", _dev(a, "a", BF16), N if lda is None else lda, _dev(b, "b", BF16), K if ldb is None else ldb, _dev(out, "out"),

@@ -515,9 +515,9 @@ def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
     regs = [blk.ffn.general] + [blk.ffn.experts[i] for i in picks]
     f = regs[0].a.weight.shape[0]
     a_pre, b_pre, hid = _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev)
-    ops.gemm_bf16(xf16, m, 3 * f, c, [W16.get(r.a.weight) for r in regs], a_pre, biases=[r.a.bias.detach() for r in regs])
-    ops.gemm_bf16(xf16, m, 3 * f, c, [W16.get(r.b.weight) for r in regs], b_pre, biases=[r.b.bias.detach() for r in regs])
-    ops.gate_fwd_bf16(a_pre, b_pre, hid)
+    # a(x) * relu(b(x)) of the three ReGLUs in ONE launch that also stores both pre-activations for the backward
+    ops.gemm_bf16_gate_fwd(xf16, m, 3 * f, c, [W16.get(r.a.weight) for r in regs], [W16.get(r.b.weight) for r in regs], hid,
+                           biases_a=[r.a.bias.detach() for r in regs], biases_b=[r.b.bias.detach() for r in regs], a_pre=a_pre, b_pre=b_pre)
     ops.gemm_bf16(hid, m, c, 3 * f, [W16.get(r.c.weight) for r in regs], y, biases=[r.c.bias.detach() for r in regs],
                   seg_mode=ops.SEG_K, addend=y)
     sv.update(regs=regs, a_pre=a_pre, b_pre=b_pre, hid=hid)
@@ -534,10 +534,9 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     f = regs[0].a.weight.shape[0]
     # ---- RandomMoE ------------------------------------------------------------------------------------
     dwc, bias_dy = grad_weight_rows16(dy16, sv["hid"], m)            # [C, 3F], [C]
-    dhid = _e16(m, 3 * f, dev=dev)
-    ops.gemm_bf16(dy16, m, 3 * f, c, [W16.get(r.c.weight, True) for r in regs], dhid)
     da, db = _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev)
-    ops.gate_bwd_bf16(dhid, sv["a_pre"], sv["b_pre"], da, db)
+    # dhid = dy . Wc with the gate's backward in the epilogue: dhid never reaches HBM
+    ops.gemm_bf16_gate_bwd(dy16, m, 3 * f, c, [W16.get(r.c.weight, True) for r in regs], sv["a_pre"], sv["b_pre"], da, db)
     dxf = torch.empty(m, c, device=dev, dtype=torch.float32)
     ops.gemm_bf16(da, m, c, 3 * f, [W16.get(r.a.weight, True) for r in regs], dxf, seg_mode=ops.SEG_K)
     ops.gemm_bf16(db, m, c, 3 * f, [W16.get(r.b.weight, True) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)

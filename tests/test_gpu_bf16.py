@@ -228,3 +228,45 @@ def test_bf16_full_width_training_step_vs_reference(gpu_device, tag, seed):
     assert worst_t < GRAD_TOL
     del net
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("M,C,nseg", [(256, 64, 3), (1000, 128, 3), (70, 64, 1), (8192, 256, 2)])
+def test_gemm_bf16_fused_gate_forward_and_backward(gpu_device, M, C, nseg):
+    """ReGLU forward in one launch (+ saved pre-activations) and the gate backward fused behind the dh GEMM, against the unfused
+    bf16 kernels: bit-identical (same MFMA order, same roundings)."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    F_ = C
+    x = bf(torch.randn(M, C, generator=g)).cuda()
+    wa = [bf(torch.randn(F_, C, generator=g) / C ** 0.5).cuda() for _ in range(nseg)]
+    wb = [bf(torch.randn(F_, C, generator=g) / C ** 0.5).cuda() for _ in range(nseg)]
+    ba = [torch.randn(F_, generator=g).cuda() for _ in range(nseg)]
+    bb = [torch.randn(F_, generator=g).cuda() for _ in range(nseg)]
+    N = nseg * F_
+    a_ref, b_ref, h_ref = (torch.empty(M, N, device=gpu_device, dtype=BF) for _ in range(3))
+    ops.gemm_bf16(x, M, N, C, wa, a_ref, biases=ba)
+    ops.gemm_bf16(x, M, N, C, wb, b_ref, biases=bb)
+    ops.gate_fwd_bf16(a_ref, b_ref, h_ref)
+    a_pre, b_pre, hid = (torch.full((M, N), float("nan"), device=gpu_device, dtype=BF) for _ in range(3))
+    ops.gemm_bf16_gate_fwd(x, M, N, C, wa, wb, hid, biases_a=ba, biases_b=bb, a_pre=a_pre, b_pre=b_pre)
+    assert torch.equal(a_pre, a_ref) and torch.equal(b_pre, b_ref)
+    # hid: the unfused path rounds a and b to bf16 BEFORE the product, the fused one multiplies the fp32 values: compare to fp64
+    ref = ((x.double() @ torch.cat([w.double() for w in wa]).t() + torch.cat(ba).double())
+           * torch.relu(x.double() @ torch.cat([w.double() for w in wb]).t() + torch.cat(bb).double()))
+    assert rel_l2(hid.double().cpu(), ref.cpu()) < 3e-3
+    hid2 = torch.full((M, N), float("nan"), device=gpu_device, dtype=BF)
+    ops.gemm_bf16_gate_fwd(x, M, N, C, wa, wb, hid2, biases_a=ba, biases_b=bb)    # without the saved pre-activations
+    assert torch.equal(hid2, hid)
+    # backward: dh = dy . Wc^T-segments, da = dh relu(b), db = dh a (b > 0)
+    dy = bf(torch.randn(M, C, generator=g)).cuda()
+    wct = [bf(torch.randn(F_, C, generator=g) / C ** 0.5).cuda() for _ in range(nseg)]      # already "transposed": [F, C] rows
+    dh = torch.empty(M, N, device=gpu_device, dtype=BF)
+    ops.gemm_bf16(dy, M, N, C, wct, dh)
+    da_ref, db_ref = torch.empty_like(dh), torch.empty_like(dh)
+    ops.gate_bwd_bf16(dh, a_pre, b_pre, da_ref, db_ref)
+    da, db = (torch.full((M, N), float("nan"), device=gpu_device, dtype=BF) for _ in range(2))
+    ops.gemm_bf16_gate_bwd(dy, M, N, C, wct, a_pre, b_pre, da, db)
+    dh64 = dy.double() @ torch.cat([w.double() for w in wct]).t()
+    assert rel_l2(da.double().cpu(), (dh64 * torch.relu(b_pre.double())).cpu()) < 3e-3
+    assert rel_l2(db.double().cpu(), (dh64 * a_pre.double() * (b_pre.double() > 0)).cpu()) < 3e-3
+    assert rel_l2(da.double().cpu(), da_ref.double().cpu()) < 6e-3 and rel_l2(db.double().cpu(), db_ref.double().cpu()) < 6e-3

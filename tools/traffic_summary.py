@@ -54,6 +54,21 @@ if __name__ == "__main__":
             tot[2] += ns
     summary = dict(gemm_launches=tot[0], gemm_hbm_bytes_per_launch=tot[1] / max(tot[0], 1),
                    gemm_avg_us=tot[2] / max(tot[0], 1) / 1e3, kernels=rows[:12])
+    # ALGORITHMIC bytes per launch of the two dominant instances at the bench workload (B = 256, latent 32x32: M = 262144 >> level,
+    # C = 128 << level, 6 / 6 / 18 / 6 SwinBlocks per level), every operand once:
+    #   gated MoE GEMM: reads x [M, C] + 2 x 3 weight matrices [C, C], writes the hidden [M, 3C]
+    #   VAE dense 3x3 conv (C >= 128 instance): reads the input once + weights, writes the output (+ reads the residual where fused)
+    blocks = [6, 6, 18, 6]
+    gate_r = sum(n * ((262144 >> (2 * i)) * (128 << i) * 4 + 6 * (128 << i) ** 2 * 4) for i, n in enumerate(blocks)) / 36.0
+    gate_w = sum(n * ((262144 >> (2 * i)) * 3 * (128 << i) * 4) for i, n in enumerate(blocks)) / 36.0
+    inst = {}
+    for r in rows:
+        if r["kernel"].startswith("gemm_stream_kernel<2, 2, 2, 1, true, 0, 0, true"):
+            inst["gated MoE GEMM"] = dict(kernel=r["kernel"], algorithmic_fetch=gate_r, algorithmic_write=gate_w,
+                                          fetch_over_algorithmic=r["fetch_bytes_x2_per_launch"] / gate_r,
+                                          write_over_algorithmic=r["write_bytes_per_launch"] / gate_w,
+                                          total_over_algorithmic=(r["fetch_bytes_x2_per_launch"] + r["write_bytes_per_launch"]) / (gate_r + gate_w))
+    summary["per_instance"] = inst
     json.dump(summary, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
     with open("profiles/%s_traffic.md" % tag, "w") as out:
         out.write("# HBM-side traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n")
