@@ -334,6 +334,11 @@ int ldm_vq_loss_bwd_f32(const float *x, const float *e, const long long *idx, co
  * The data gradient is the same call on dy with the flipped, in/out-swapped filter. */
 int ldm_gconv3x3_bf16(const void *x, const void *w, const float *bias, const float *addend, float *out, int B, int H, int W, int C, void *stream);
 
+/* Weight gradient of the same layer from bf16 x and dy [B*H*W, C]: out_planes[(s * 4 + w)][C][288] fp32 (288 = tap * 32 + ci),
+ * s < splits, w < 4; the caller sums the 4 * splits planes (ldm_reduce_partials_f32).  ldm_gconv3x3_wgrad_bf16_splits suggests splits. */
+int ldm_gconv3x3_wgrad_bf16_splits(int B, int H, int W, int C);
+int ldm_gconv3x3_wgrad_bf16(const void *x, const void *dy, float *out_planes, int B, int H, int W, int C, int splits, void *stream);
+
 /* All bf16 weight copies of a training step in one launch: job j = fp32 row-major [rows, cols] -> bf16 copy `dst` [rows, cols]
  * and / or transposed bf16 copy `dst_t` [cols, rows] (NULL = not wanted).  `items` is a HOST array; `table_dev` a DEVICE scratch
  * of ldm_multi_cast_table_bytes(njobs) that holds the uploaded job table between calls: pass rebuild != 0 on the first call and

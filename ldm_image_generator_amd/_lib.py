@@ -140,6 +140,8 @@ SIGNATURES = {
     "ldm_channelnorm_film_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_channelnorm_film_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_gconv3x3_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_gconv3x3_wgrad_bf16_splits": (_I, [_I, _I, _I, _I]),
+    "ldm_gconv3x3_wgrad_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_vq_quantize_f32": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ldm_vq_embed_f32": (_I, [_P, _P, _P, _L, _I, _P]),
     "ldm_vq_loss_f32": (_I, [_P, _P, _L, _P, _P]),

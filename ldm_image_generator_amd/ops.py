@@ -496,6 +496,15 @@ def gconv3x3_bf16(x16, w16, bias, addend, out, B, H, W, C):
     return out
 
 
+def gconv3x3_wgrad_bf16(x16, dy16, B, H, W, C):
+    """dW [C, 288] fp32 (row = output channel, 288 = tap * 32 + input channel) of the grouped 3x3 conv from bf16 x and dy rows."""
+    lib = _lib.load()
+    sp = lib.ldm_gconv3x3_wgrad_bf16_splits(B, H, W, C)
+    planes = torch.empty(4 * sp, C, 288, device=x16.device, dtype=torch.float32)
+    _call("ldm_gconv3x3_wgrad_bf16", _dev(x16, "x", BF16), _dev(dy16, "dy", BF16), _dev(planes, "planes"), B, H, W, C, sp)
+    return reduce_partials(planes, 4 * sp, C * 288, torch.empty(C, 288, device=x16.device, dtype=torch.float32))
+
+
 def film_hidden(p_rows, t_rows, out, B, HW, N):
     """out[b, pixel, :] = relu(P[pixel] + T[b]) -- Encodings.proj1 in separable form; ``out`` fp32 or bf16 [B*HW, N]."""
     bf = out.dtype == BF16

@@ -496,7 +496,8 @@ def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
     b, h, w = shape
     m, c = rows.shape
     dev = rows.device
-    xf = torch.empty_like(rows)                         # fp32: grouped conv, attention's float "mask"
+    # the fp32 copy of the normalised input is only read by window attention (its float "mask" and the fp32 attention kernels)
+    xf = torch.empty_like(rows) if blk.attention_flag else None
     xf16 = _e16(m, c, dev=dev)
     ops.channelnorm_film_bf16(rows, film, ctx.slot, xf, xf16, b, h * w, c, blk.norm.eps)
     y = torch.empty_like(rows)
@@ -567,7 +568,7 @@ def block_backward16(sv, dy, dy16, ctx, grads):
         grads.add(att.in_proj_weight, dwi)
         grads.add(att.in_proj_bias, ops.add_(dbi.clone(), dpad))
     # ---- grouped 3x3 conv: data gradient on the bf16 matrix cores, weight gradient by the fp32 kernel ----------
-    _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=dy16)
+    _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=dy16, xf16=xf16)
     # ---- ChannelNorm + FiLM, residual ---------------------------------------------------------------------
     film = sv["film"]
     dfilm16 = _e16(film.shape[0], film.shape[1], dev=dev)
@@ -578,17 +579,21 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     return dx, dx16
 
 
-def _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=None):
-    """data gradient (accumulated into dxf) and weight / bias gradient of the grouped 3x3 conv (unet.py:30,44); the data
-    gradient takes bf16 operands when ``dy16`` (the bf16 shadow of dy) is given."""
+def _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=None, xf16=None):
+    """data gradient (accumulated into dxf) and weight / bias gradient of the grouped 3x3 conv (unet.py:30,44); both take bf16
+    operands when ``dy16`` / ``xf16`` (the bf16 shadows of dy and of the block's normalised input) are given."""
     b, h, w = shape
-    m, c = xf.shape
-    dev = xf.device
+    m, c = dy.shape
+    dev = dy.device
     g = c // 32
     wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
     wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
     if dy16 is not None:
         ops.gconv3x3_bf16(dy16, ops.cast_bf16(wrot), None, dxf, dxf, b, h, w, c)
+        dwconv = ops.gconv3x3_wgrad_bf16(xf16, dy16, b, h, w, c)
+        grads.add(blk.conv.weight, dwconv.reshape(c, 3, 3, 32).permute(0, 3, 1, 2))
+        grads.add(blk.conv.bias, bias_dy.clone())
+        return
     else:
         ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
                  cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)

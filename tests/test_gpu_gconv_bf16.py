@@ -36,3 +36,9 @@ def test_gconv3x3_bf16_forward_and_data_gradient(gpu_device, B, H, W, C):
     ops.gconv3x3_bf16(dy.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda(), wrot, None, acc, acc, B, H, W, C)
     want = xin.grad.permute(0, 2, 3, 1).reshape(-1, C) + acc0.double()
     assert rel_l2(acc.cpu(), want) < 1e-5
+    # weight gradient (zero-padded index space, transposing LDS reads): dW[co][tap][ci] vs autograd on the same bf16 numbers
+    wz = torch.zeros(C, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), wz, None, padding=1, groups=C // 32).backward(dy.double())
+    dw = ops.gconv3x3_wgrad_bf16(rows, dy.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda(), B, H, W, C)
+    got_w = dw.cpu().reshape(C, 3, 3, 32).permute(0, 3, 1, 2)
+    assert rel_l2(got_w, wz.grad) < 1e-5
