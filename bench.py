@@ -220,11 +220,13 @@ def main():
         from ldm_image_generator_amd import train as ltrain
         torch.cuda.empty_cache()
         net.train(True)
-        opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)                       # train_ldm.py:67
+        # train_ldm.py:67 constructs torch.optim.AdamW; its fused=True flavour (one kernel per parameter chunk, same update rule)
+        # keeps the host out of the way: the foreach default costs 10-28 ms of host-bound time per step on 1376 tensors
+        opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4, fused=True)
         xb = torch.randn(args.train_batch, 8, args.train_latent, args.train_latent,
                          generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
         train_step = {"unit": "samples/s", "config": {"workload": "train_ldm step, latents [%d, 8, %d, %d] per GPU, UNet(385.7M) train mode, "
-                                                                  "L1 loss, AdamW" % (args.train_batch, args.train_latent, args.train_latent),
+                                                                  "L1 loss, torch.optim.AdamW(fused=True)" % (args.train_batch, args.train_latent, args.train_latent),
                                                       "global_batch": args.train_batch * world, "steps": args.train_steps, "warmup": 1}}
         for prec in getattr(ltrain, "PRECISIONS", ("f32",)):
             ltrain.set_precision(net, prec) if hasattr(ltrain, "set_precision") else None

@@ -14,7 +14,7 @@ Every GEMM-shaped gradient is an ``ldm_gemm_f32`` launch:
 """
 import torch
 
-from . import ops
+from . import ops, weights
 
 
 def _T(x, rows=None):
@@ -42,7 +42,7 @@ class _WeightT:
         self.cache = {}
 
     def get(self, w2d, key_tensor):
-        key = (key_tensor.data_ptr(), key_tensor._version)
+        key = weights.key(key_tensor)
         hit = self.cache.get(id(key_tensor))
         if hit is None or hit[0] != key:
             hit = (key, _T(w2d.contiguous()))
@@ -399,7 +399,7 @@ class _Weight16:
         from . import _lib
         plist = self._gemm_weights(net)
         ptrs = tuple(p.data_ptr() for p in plist)
-        stamp = (ptrs, sum(p._version for p in plist))
+        stamp = (ptrs, sum(p._version for p in plist), weights.GENERATION[0])
         if self.net_id == id(net) and self.stamp == stamp:
             return
         lib = _lib.load()
@@ -430,7 +430,7 @@ class _Weight16:
         if hit is not None and hit[0] == p.data_ptr():                          # a view into the step's table
             return hit[1 + int(transposed)]
         # a parameter outside the refreshed network (module-level use, tests): one cast per parameter version
-        key = (p.data_ptr(), p._version)
+        key = weights.key(p)
         lone = self.lone.get(id(p))
         if lone is None or lone[0] != key:
             w = _w2d(p).contiguous()

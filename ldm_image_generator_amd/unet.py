@@ -20,7 +20,7 @@ import random
 import torch
 import torch.nn as nn
 
-from . import ops, sinusoidal
+from . import ops, sinusoidal, weights
 from .attention import CrossAttention, WindowAttention
 from .modules import ChannelNorm, RandomMoE, from_rows, to_rows, w2d
 from .sinusoidal import PositionalEncoding2d, TimeEncoding2d
@@ -120,7 +120,7 @@ class SwinBlock(nn.Module):
     def _conv_weight(self):
         """[C, 32, 3, 3] -> [C][tap][32] (K contiguous for the implicit-GEMM), cached per weight version."""
         w = self.conv.weight
-        key = (w.data_ptr(), w._version)
+        key = weights.key(w)
         if self._packed is None or self._packed[0] != key:
             c = w.shape[0]
             self._packed = (key, w.detach().permute(0, 2, 3, 1).reshape(c, 9 * w.shape[1]).contiguous())
@@ -269,7 +269,7 @@ class UNet(nn.Module):
         if self._plan is not None:
             order, captured = self._plan[3], self._plan[4]
             key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured),
-                   tuple(blk.conv.weight._version for blk in order))
+                   tuple(blk.conv.weight._version for blk in order), weights.GENERATION[0])
             if self._plan[0] == key:
                 return self._plan[1]
         order = [blk for l in self.encoder_stages for blk in l.stage.blocks] + [blk for l in self.decoder_stages for blk in l.stage.blocks]
@@ -319,7 +319,8 @@ class UNet(nn.Module):
         plan.head_w, plan.head_b = ptr(self.decoder_last.weight), ptr(self.decoder_last.bias)
         plan.blocks = ctypes.cast(blocks, ctypes.POINTER(UNetBlockDesc))
         keep.append(blocks)
-        key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured), tuple(blk.conv.weight._version for blk in order))
+        key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured), tuple(blk.conv.weight._version for blk in order),
+               weights.GENERATION[0])
         self._plan = (key, plan, keep, order, captured)
         return plan
 
@@ -327,6 +328,7 @@ class UNet(nn.Module):
         """Drop every derived copy of the weights (native plan, pointer tables, packed grouped-conv filters).  Needed only after
         writing weights in place through ``.data`` (p.data.copy_(), EMA swaps, clipping), which bumps no version counter; updates
         through the Parameter itself (optimizer steps, load_state_dict, p.copy_ under no_grad) are tracked automatically."""
+        weights.bump()                     # every version-keyed copy (transposed / bf16 weights of the training step too)
         self._plan = None
         self._tables = {}
         for stack in list(self.encoder_stages) + list(self.decoder_stages):

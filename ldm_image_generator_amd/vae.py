@@ -14,7 +14,7 @@ the forward of ``VAE.calclate_loss``; the ``Discriminator`` and the Encoder / De
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, weights
 from .modules import from_rows, to_rows, w2d
 
 
@@ -27,7 +27,7 @@ class _PackedWeight:
         self.val = None
 
     def get(self, w):
-        key = (w.data_ptr(), w._version)
+        key = weights.key(w)
         if key != self.key:
             self.key, self.val = key, self.fn(w.detach()).contiguous()
         return self.val

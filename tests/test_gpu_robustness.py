@@ -53,6 +53,38 @@ def test_native_plan_follows_weight_replacement_and_data_writes(gpu_device):
     assert rel_l2(y3.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_fused_adamw_does_not_leave_stale_weight_copies(gpu_device, precision):
+    """torch.optim.AdamW(fused=True) updates parameters WITHOUT bumping their version counters; every derived copy (transposed,
+    packed, bf16) must still follow (weights.GENERATION via the optimizer-step hook): two training steps with the fused optimizer
+    equal two steps with the foreach one."""
+    from ldm_image_generator_amd import train
+    from ldm_image_generator_amd.train import L1LossFunction
+    from ldm_image_generator_amd.unet import UNet
+    cfg = dict(input_channels=8, stages=[1, 1], channels=[64, 128])
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 8, 16, 16, generator=gen).cuda()
+    e = torch.randn(4, 8, 16, 16, generator=gen).cuda()
+    t = torch.tensor([3, 500, 999, 40]).cuda()
+    losses = {}
+    for fused in (False, True):
+        net = formula(UNet(**cfg)).train()
+        train.set_precision(net, precision)
+        opt = torch.optim.AdamW(net.parameters(), lr=3e-3, fused=fused)
+        out = []
+        for step in range(3):
+            random.seed(20 + step)
+            opt.zero_grad()
+            loss = L1LossFunction.apply(net(x=x, time=t, condition=None), e)
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        losses[fused] = out
+    assert losses[True][0] == pytest.approx(losses[False][0], rel=1e-6)
+    for a, b in zip(losses[True][1:], losses[False][1:]):              # later steps see the updated weights in EVERY kernel
+        assert a == pytest.approx(b, rel=2e-3 if precision == "bf16" else 1e-4)
+
+
 def test_training_path_returns_input_gradient(gpu_device):
     """x.requires_grad (trainable encoder upstream, gradient guidance): dL/dx through the hand-written backward == oracle autograd."""
     from ldm_image_generator_amd import synth

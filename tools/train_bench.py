@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--latent", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--gemm-variant", type=int, default=1, help="1 = exact-fp32 stream schedule, 2 = bf16x3 split consumer")
+ap.add_argument("--fused-adamw", type=int, default=1, help="1 (default, as bench.py): torch.optim.AdamW(fused=True); 0: the foreach default")
 ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="operand precision of the training step (train.set_precision)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -27,7 +28,7 @@ net = net.to(dev).train()
 from ldm_image_generator_amd import train as ltrain  # noqa: E402
 ltrain.set_precision(net, args.precision)
 ddpm = DDPM(model=net)
-opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)
+opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4, fused=bool(args.fused_adamw))
 x = torch.randn(args.batch, 8, args.latent, args.latent, generator=torch.Generator().manual_seed(0)).to(dev)
 ldist.train_step(ddpm, opt, x, 0, 1)
 torch.cuda.synchronize()
