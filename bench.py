@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6290 measured with a float4 copy)
 UNET_GFLOP_PER_SAMPLE_STEP = 13.74  # SURVEY.md 8(d), algorithmic minimum @ latent 32x32
 DECODE_GFLOP_PER_IMAGE = 80.586
 PROF_CLASSES = {0: "ldm_gemm_f32", 1: "ldm_gemm_tn_f32", 2: "ldm_gconv3x3_wgrad_f32", 3: "ldm_gemm_bf16", 4: "ldm_gemm_tn_bf16",
@@ -243,21 +244,31 @@ def main():
                    "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
             if rank == 0:
                 per, tot_ms, tot_fl = {}, 0.0, 0.0
+                tot_by = 0.0
                 for cls, name in PROF_CLASSES.items():
                     n, ms, fl = ops.prof_read_class(cls)
                     if n:
+                        by = ops.prof_read_bytes(cls)
                         per[name] = {"launches_per_step": n // args.train_steps, "ms_per_step": ms / args.train_steps,
-                                     "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None}
+                                     "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                                     "algorithmic_gb_per_s": by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None}
                         tot_ms += ms
                         tot_fl += fl
+                        tot_by += by
                 ops.prof_read()
                 peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else FP32_MFMA_PEAK_TFLOPS
                 ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+                gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
                 leg["executed_gflop_per_step"] = tot_fl / 1e9 / args.train_steps
                 leg["mfma_kernel_ms_per_step"] = tot_ms / args.train_steps
-                leg["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                   "kernel": "all MFMA kernels of the step (NT, TN weight-gradient, grouped-conv weight-gradient), hipEvents per launch",
-                                   "per_kernel": per}
+                mfma_view = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+                hbm_view = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "note": "algorithmic operand bytes of the MFMA kernels (every operand once) / their kernel time"}
+                # fp32 operands: the exact-fp32 MFMA paces the step; bf16 operands: the same GEMMs are 16x cheaper and the step
+                # is paced by operand traffic (ridge 2500 / 6.3 = 400 FLOP/B vs 96-384 FLOP/B of these layers)
+                leg["roofline"] = dict(hbm_view if prec == "bf16" else mfma_view)
+                leg["roofline"].update({"kernel": "all MFMA kernels of the step (NT, TN weight-gradient, grouped conv), hipEvents per launch",
+                                        "other_view": mfma_view if prec == "bf16" else hbm_view, "per_kernel": per})
             ops.prof_enable(False)
             train_step[prec] = leg
         if hasattr(ltrain, "set_precision"):

@@ -554,7 +554,8 @@ extern "C" int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *ou
         (void)hipFuncSetAttribute((const void *)gconv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
-    void *rec = ldm_prof_begin(LDM_PROF_GCONV_WG, 2.0 * (double)M * C * 288.0, (hipStream_t)stream);
+    void *rec = ldm_prof_begin(LDM_PROF_GCONV_WG, 2.0 * (double)M * C * 288.0, (hipStream_t)stream,
+                               8.0 * (double)M * C + 4.0 * splits * (double)C * 288.0);
     hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(C / 32, splits), dim3(256), smem, (hipStream_t)stream, x, dy, out_planes, (int)M, H, W, C,
                        (int)(M / splits), 1.0f / (float)W, 1.0f / (float)H);
     ldm_prof_end(rec, (hipStream_t)stream);

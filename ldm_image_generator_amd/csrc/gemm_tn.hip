@@ -154,7 +154,8 @@ extern "C" int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, lo
         (void)hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)N * K, (hipStream_t)stream);
+    void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)N * K, (hipStream_t)stream,
+                               4.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_gemm_tn_f32");

@@ -214,6 +214,38 @@ def test_calculate_loss_end_to_end_and_optimizer_step(gpu_device):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_one_epoch_of_train_ddpm_on_its_own_shape(gpu_device, precision):
+    """BASELINE configs[0] on the HIP path: train_ddpm.py's loop (train_ddpm.py:11-16,28,31-45) -- default-width
+    UNet(input_channels=3) inside DDPM, 64 synthetic 32x32 RGB images, batch 16, RAdam lr 1e-4, one epoch = 4 iterations.
+    32x32 pixels put the deepest stage at 4x4 (attention windows clipped to the image); every iteration must give a finite
+    loss and a finite update of every parameter that received a gradient."""
+    from ldm_image_generator_amd import train
+    from ldm_image_generator_amd.ddpm import DDPM
+    from ldm_image_generator_amd.unet import UNet
+    net = formula(UNet(input_channels=3)).train()
+    train.set_precision(net, precision)
+    d = DDPM(model=net)
+    opt = torch.optim.RAdam(d.parameters(), lr=1e-4)
+    images = (torch.rand(64, 3, 32, 32, generator=torch.Generator().manual_seed(0)) * 2 - 1)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    random.seed(1)
+    torch.manual_seed(1)
+    losses = []
+    for it in range(4):
+        opt.zero_grad()
+        loss = d.calculate_loss(images[16 * it:16 * it + 16].cuda())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and all(0.0 < v < 10.0 for v in losses), losses
+    moved = 0
+    for k, p in net.named_parameters():
+        assert bool(torch.isfinite(p).all()), k
+        moved += int(not torch.equal(p.detach(), before[k]))
+    assert moved > 500
+
+
 def test_unet_gradients_vs_oracle_autograd(gpu_device):
     """Fresh inputs, per-sample timesteps, eval mode (all blocks): every parameter gradient vs oracle autograd."""
     from ldm_image_generator_amd import synth
