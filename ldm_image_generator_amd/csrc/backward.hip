@@ -89,6 +89,45 @@ __global__ void reduce_partials_kernel(const float *__restrict__ parts, float *_
     out[i] = s;
 }
 
+// Same sum for n % 4 == 0, laid out for memory-level parallelism: a block owns 64 float4 columns, its four waves each sum a
+// contiguous quarter of the S planes (four independent 16-byte loads in flight per lane) and wave 0 adds the four quarter sums
+// in plane order.  Fixed association ((q0 + q1) + q2) + q3, no atomics: the result does not depend on scheduling.  The scalar
+// kernel above had one dependent 4-byte load chain per element: 15 us per launch on average over the ~330 weight-gradient
+// reductions of a training step (S = 4 ... 128 planes of 50 k ... 3 M elements), most of it latency.
+__global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const f32x4 *__restrict__ parts, f32x4 *__restrict__ out, int S, long long n4)
+{
+    __shared__ f32x4 part[3][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    const bool live = i < n4;
+    const int s0 = (int)((long long)S * q / 4), s1 = (int)((long long)S * (q + 1) / 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const f32x4 *src = parts + (long long)s0 * n4 + i;
+        int k = s0;
+        for (; k + 4 <= s1; k += 4) {
+            const f32x4 v0 = src[0], v1 = src[n4], v2 = src[2 * n4], v3 = src[3 * n4];
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+            src += 4 * n4;
+        }
+        for (; k < s1; ++k) {
+            acc += src[0];
+            src += n4;
+        }
+    }
+    if (q) part[q - 1][lane] = acc;
+    __syncthreads();
+    if (q == 0 && live) {
+        acc += part[0][lane];
+        acc += part[1][lane];
+        acc += part[2][lane];
+        out[i] = acc;
+    }
+}
+
 // ---- ChannelNorm + FiLM backward ----------------------------------------------------------------
 // xf = xn * mul + bias, xn = (x - mean) / sqrt(var_unbiased + eps)
 //   dfilm[slot, pix, c] += dxf * xn ; dfilm[slot, pix, C + c] += dxf            (atomic: samples sharing a slot)
@@ -649,7 +688,11 @@ extern "C" int ldm_transpose_colsum_f32(const float *x, float *out, float *csum,
 extern "C" int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream)
 {
     LDM_REQUIRE(parts && out && S > 0 && n > 0, "ldm_reduce_partials_f32: bad arguments");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, parts, out, S, n);
+    if (n % 4 == 0 && S >= 4 && ldm_aligned16(parts) && ldm_aligned16(out))
+        hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3(blocks_for(n / 4, 64)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)parts,
+                           (f32x4 *)out, S, n / 4);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, parts, out, S, n);
     LDM_CHECK_LAUNCH("ldm_reduce_partials_f32");
     return LDM_OK;
 }

@@ -46,6 +46,21 @@ def test_gemm_tn_weight_gradient_kernel(gpu_device, M, N, K, S):
     assert rel_l2(out.double().cpu(), (wide[:, :N].double().t() @ x.double()).cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("S,n", [(1, 4096), (3, 1000), (4, 256), (5, 49152), (7, 260), (128, 49152), (13, 3 * 1024 * 1024), (64, 37)])
+def test_reduce_partials_fixed_order_sum(gpu_device, S, n):
+    """Sum of S partial planes: vectorised kernel (n % 4 == 0, S >= 4: four quarter sums in plane order) and the scalar one;
+    deterministic (two runs bit-equal), fp32-accurate against the float64 sum."""
+    from ldm_image_generator_amd import ops
+    parts = torch.randn(S, n, generator=torch.Generator().manual_seed(S * 7 + n)).cuda()
+    out = torch.full((n,), float("nan"), device=gpu_device)
+    again = torch.full((n,), float("nan"), device=gpu_device)
+    ops.reduce_partials(parts, S, n, out)
+    ops.reduce_partials(parts, S, n, again)
+    assert torch.equal(out, again)
+    ref = parts.double().sum(0)
+    assert float((out.double() - ref).abs().max()) <= 4e-7 * float(parts.abs().double().sum(0).max())
+
+
 @pytest.mark.parametrize("B,H,W,C,S", [(2, 8, 8, 64, 1), (4, 16, 16, 128, 2), (32, 4, 4, 256, 4), (1, 6, 64, 32, 1), (3, 32, 32, 64, 8)])
 def test_grouped_conv_weight_gradient_kernel(gpu_device, B, H, W, C, S):
     """dW of the 32-per-group 3x3 conv from the row-major activations (no transposed im2col) vs autograd."""
