@@ -54,6 +54,55 @@ def test_gemm_bf16(gpu_device, M, N, K, nseg, seg_mode, act, addend, out16):
     assert err < (3e-3 if out16 else 1e-5), err
 
 
+@pytest.mark.parametrize("M,N,K,nseg,seg_mode,act,addend,out16", [
+    (256, 256, 64, 1, 0, 0, False, False),         # one tile, two steps: ring never full
+    (512, 256, 128, 1, 0, 0, False, True),         # four steps: exactly one ring
+    (1024, 768, 256, 3, 0, 1, False, True),        # three N-segments of 256 (experts by pointer), relu, bf16 out
+    (768, 512, 1536, 3, 1, 0, True, False),        # K-segments + fp32 addend in place (the MoE's second GEMM)
+    (2048, 1024, 2048, 1, 0, 0, False, False),     # the Encodings MLP shapes
+    (2048, 2048, 1024, 1, 0, 0, False, True),
+    (65536, 512, 512, 1, 0, 3, True, False),       # 512 tiles on 256 workgroups: the stream across tile boundaries, leaky relu
+    (16384, 256, 192, 1, 0, 0, False, True),       # six steps per tile
+])
+def test_gemm_bf16_ring_kernel_bit_identical_to_stream_kernel(gpu_device, M, N, K, nseg, seg_mode, act, addend, out16):
+    """256 x 256 four-stage ring kernel (gemm_bf16_ring.hip) == 128 x 128 stream kernel, bit for bit (same 16-k slices in the
+    same order), and both are right against float64."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = bf(torch.randn(M, K, generator=g)).cuda()
+    if seg_mode == 0:
+        ws = [bf(torch.randn(N // nseg, K, generator=g) / K ** 0.5).cuda() for _ in range(nseg)]
+        wfull = torch.cat([w.double() for w in ws], 0)
+        biases = [torch.randn(N // nseg, generator=g).cuda() for _ in range(nseg)]
+        bfull = torch.cat([b_.double() for b_ in biases])
+    else:
+        ws = [bf(torch.randn(N, K // nseg, generator=g) / K ** 0.5).cuda() for _ in range(nseg)]
+        wfull = torch.cat([w.double() for w in ws], 1)
+        biases = [torch.randn(N, generator=g).cuda() for _ in range(nseg)]
+        bfull = sum(b_.double() for b_ in biases)
+    base = torch.randn(M, N, generator=g).cuda() if addend else None
+    outs = {}
+    old = ops.gemm_bf16_ring(1)
+    try:
+        for mode in (0, 2):
+            ops.gemm_bf16_ring(mode)
+            out = base.clone() if addend else torch.full((M, N), float("nan"), device=gpu_device, dtype=BF if out16 else torch.float32)
+            ops.gemm_bf16(a, M, N, K, ws, out, biases=biases, seg_mode=seg_mode, act=act, slope=0.2, addend=out if addend else None)
+            outs[mode] = out
+    finally:
+        ops.gemm_bf16_ring(old)
+    assert torch.equal(outs[0], outs[2])
+    if M * N * K <= 2 ** 33:
+        ref = a.double() @ wfull.t() + bfull
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 3:
+            ref = torch.where(ref > 0, ref, ref * 0.2)
+        if addend:
+            ref = ref + base.double()
+        assert rel_l2(outs[2].double().cpu(), ref.cpu()) < (3e-3 if out16 else 1e-5)
+
+
 @pytest.mark.parametrize("M,N,K,S", [(64, 128, 128, 1), (4096, 256, 128, 4), (2048, 128, 384, 2), (192, 384, 256, 3), (65536, 128, 128, 8)])
 def test_gemm_tn_bf16(gpu_device, M, N, K, S):
     from ldm_image_generator_amd import ops
