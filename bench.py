@@ -243,7 +243,7 @@ def main():
             leg = {"ms_per_step": dts / args.train_steps * 1e3, "value": args.train_batch * world * args.train_steps / dts,
                    "loss": float(loss.detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
             if prec == "bf16":
-                leg["bf16_ring"] = ops.gemm_bf16_ring(-1)      # 1 = 256x256 ring kernel for the large plain NT GEMMs (bit-identical to 0)
+                leg["gemm_ring"] = ops.gemm_ring(-1)      # 1 = 256x256 ring kernel for the large plain NT GEMMs (bit-identical to 0)
             if rank == 0:
                 per, tot_ms, tot_fl = {}, 0.0, 0.0
                 tot_by = 0.0

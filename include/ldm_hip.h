@@ -126,10 +126,11 @@ int ldm_gemm_variant(int v);
 /* epilogue of the stream schedule for plain-rows outputs: 1 (default) = through LDS, 16 bytes per lane per store;
  * 0 = direct from the MFMA layout, 4 bytes per lane.  Bit-identical results; A/B knob.  Returns the previous setting. */
 int ldm_gemm_wide_epilogue(int v);
-/* schedule of ldm_gemm_bf16 for plain problems with M, N (and N-segments) multiples of 256: 1 (default) = the 256 x 256
- * four-stage ring kernel when at least 192 tiles exist, 0 = always the 128 x 128 stream kernel, 2 = the ring kernel whenever
- * the shape is legal.  Bit-identical results; A/B and test knob.  Returns the previous setting (other v only queries). */
-int ldm_gemm_bf16_ring(int v);
+/* schedule of ldm_gemm_f32 / ldm_gemm_bf16 for rows-in / rows-out problems with M a multiple of 256 and N (and N-segments) a
+ * multiple of 128: 1 (default) = the one-workgroup-per-CU ring kernel (256 x 256 / 256 x 128 tiles, four-stage LDS ring) when at
+ * least 192 tiles exist, 0 = always the 128-row stream kernel, 2 = the ring kernel whenever the shape is legal.  Bit-identical
+ * results; A/B and test knob.  Returns the previous setting (other v only queries). */
+int ldm_gemm_ring(int v);
 
 /* hot-kernel timing for bench.py: when enabled every ldm_gemm_f32 launch is
  * bracketed by hipEvents on ITS stream; ldm_prof_read synchronises those events

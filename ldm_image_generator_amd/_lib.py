@@ -88,7 +88,7 @@ SIGNATURES = {
     "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "ldm_gemm_variant": (_I, [_I]),
     "ldm_gemm_wide_epilogue": (_I, [_I]),
-    "ldm_gemm_bf16_ring": (_I, [_I]),
+    "ldm_gemm_ring": (_I, [_I]),
     "ldm_unet_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(UNetPlanDesc), _I, _I, _I, _I]),
     "ldm_unet_forward_f32": (_I, [ctypes.POINTER(UNetPlanDesc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I, _P,
                                   ctypes.c_size_t, _P, _P]),
@@ -182,9 +182,9 @@ def load():
     v = os.environ.get("LDM_GEMM_VARIANT")            # opt-in GEMM schedule for a whole process (see ldm_gemm_variant)
     if v is not None:
         lib.ldm_gemm_variant(int(v))
-    v = os.environ.get("LDM_BF16_RING")               # A/B: 0 = never the 256 x 256 ring kernel, 2 = whenever legal (see ldm_gemm_bf16_ring)
+    v = os.environ.get("LDM_GEMM_RING")               # A/B: 0 = never the 256-row ring kernel, 2 = whenever legal (see ldm_gemm_ring)
     if v is not None:
-        lib.ldm_gemm_bf16_ring(int(v))
+        lib.ldm_gemm_ring(int(v))
     return lib
 
 

@@ -199,6 +199,7 @@ int g_variant = 1;      // 0: tile-per-block kernel, 1: persistent LDS-DMA strea
 }  // namespace
 
 int ldm_gemm_stream_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st, bool split);
+int ldm_gemm_ring_dispatch_f32(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st);      // gemm_ring.hip
 int ldm_gconv3x3_dispatch(const ldmgemm::GemmP &p, int groups, bool gate, int amode, hipStream_t st);
 
 namespace {
@@ -206,6 +207,7 @@ namespace {
 void launch_any(const GemmP &p, int groups, bool gate, int a_mode, hipStream_t st)
 {
     if (g_variant >= 1 && ldm_gconv3x3_dispatch(p, groups, gate, a_mode, st)) return;
+    if (g_variant == 1 && ldm_gemm_ring_dispatch_f32(p, groups, gate, a_mode, st)) return;       // large rows problems: 256-row tiles, one workgroup per CU
     if (g_variant >= 1 && ldm_gemm_stream_dispatch(p, groups, gate, a_mode, st, g_variant == 2)) return;
     if (gate)
         dispatch<true, LDM_A_ROWS>(p, groups, st);

@@ -10,7 +10,7 @@
 using namespace ldmgemm;
 
 int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate);
-int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st);      // gemm_bf16_ring.hip: 256 x 256 tiles, deep ring
+int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st);      // gemm_ring.hip: 256-row tiles, one workgroup per CU, four-stage ring
 
 namespace {
 

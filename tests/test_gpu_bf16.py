@@ -82,15 +82,15 @@ def test_gemm_bf16_ring_kernel_bit_identical_to_stream_kernel(gpu_device, M, N, 
         bfull = sum(b_.double() for b_ in biases)
     base = torch.randn(M, N, generator=g).cuda() if addend else None
     outs = {}
-    old = ops.gemm_bf16_ring(1)
+    old = ops.gemm_ring(1)
     try:
         for mode in (0, 2):
-            ops.gemm_bf16_ring(mode)
+            ops.gemm_ring(mode)
             out = base.clone() if addend else torch.full((M, N), float("nan"), device=gpu_device, dtype=BF if out16 else torch.float32)
             ops.gemm_bf16(a, M, N, K, ws, out, biases=biases, seg_mode=seg_mode, act=act, slope=0.2, addend=out if addend else None)
             outs[mode] = out
     finally:
-        ops.gemm_bf16_ring(old)
+        ops.gemm_ring(old)
     assert torch.equal(outs[0], outs[2])
     if M * N * K <= 2 ** 33:
         ref = a.double() @ wfull.t() + bfull

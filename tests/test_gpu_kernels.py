@@ -442,3 +442,65 @@ def test_gemm_split_k_small_m(ops, gpu_device, M, N, K, mode):
         ref = a.double() @ w.double().t() + b.double()
         ref = (torch.relu(ref) if mode == "relu" else ref) + add.double()
     assert rel_l2(out.cpu(), ref) < KTOL
+
+
+@pytest.mark.parametrize("M,N,K,mode", [
+    (256, 256, 32, "plain"),            # one tile, two 16-k steps: ring never full
+    (512, 128, 64, "plain128"),         # 256 x 128 tiles (one accumulator column per wave), four steps = exactly one ring
+    (768, 384, 128, "nseg128"),         # three N-segments of 128 (QKV-like at C = 128): 256 x 128 tiles
+    (1024, 768, 256, "nseg"),           # three N-segments of 256: 256 x 256 tiles, relu
+    (768, 512, 1536, "kseg"),           # K-segments + bias sum + addend in place (the MoE's second GEMM)
+    (2048, 384, 128, "gate"),           # ReGLU pair at C = 128: three experts by pointer, 128 hidden columns per tile
+    (512, 1536, 512, "gate"),
+    (65536, 256, 256, "lrelu"),         # 256 tiles on 256 workgroups ... and
+    (131072, 128, 384, "kseg128"),      # ... 512 tiles of 256 x 128: the stream across tile boundaries, K-segments of 128
+])
+def test_gemm_ring_kernel_fp32_bit_identical_to_stream_kernel(ops, gpu_device, M, N, K, mode):
+    """One-workgroup-per-CU ring kernel (gemm_ring.hip, exact fp32) == the 128-row stream kernel bit for bit (same k pairing and
+    order), and right against float64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    kw, ref = {}, None
+    ad = a.double()
+    if mode in ("plain", "plain128", "lrelu"):
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        ws, kw = [w], dict(biases=[b])
+        ref = ad @ w.double().t() + b.double()
+        if mode == "lrelu":
+            kw.update(act=ops.ACT_LRELU, slope=0.2)
+            ref = torch.where(ref > 0, ref, ref * 0.2)
+    elif mode in ("nseg", "nseg128"):
+        ws = [(torch.randn(N // 3, K, generator=g) * K ** -0.5).cuda() for _ in range(3)]
+        bs = [torch.randn(N // 3, generator=g).cuda() for _ in range(3)]
+        kw = dict(biases=bs, act=ops.ACT_RELU)
+        ref = torch.relu(torch.cat([ad @ w.double().t() + b.double() for w, b in zip(ws, bs)], 1))
+    elif mode in ("kseg", "kseg128"):
+        c = K // 3
+        ws = [(torch.randn(N, c, generator=g) * K ** -0.5).cuda() for _ in range(3)]
+        bs = [torch.randn(N, generator=g).cuda() for _ in range(3)]
+        kw = dict(biases=bs, seg_mode=ops.SEG_K)
+        ref = sum(ad[:, i * c:(i + 1) * c] @ ws[i].double().t() + bs[i].double() for i in range(3))
+    else:
+        f = N // 3
+        ws = [(torch.randn(f, K, generator=g) * K ** -0.5).cuda() for _ in range(3)]
+        wb = [(torch.randn(f, K, generator=g) * K ** -0.5).cuda() for _ in range(3)]
+        ba = [torch.randn(f, generator=g).cuda() for _ in range(3)]
+        bb = [torch.randn(f, generator=g).cuda() for _ in range(3)]
+        kw = dict(weights2=wb, biases=ba, biases2=bb, act=ops.ACT_GATE)
+        ref = torch.cat([(ad @ ws[i].double().t() + ba[i].double()) * torch.relu(ad @ wb[i].double().t() + bb[i].double()) for i in range(3)], 1)
+    base = torch.randn(M, N, generator=g).cuda() if mode.startswith("kseg") else None
+    if base is not None:
+        ref = ref + base.double()
+    outs = {}
+    old = ops.gemm_ring(1)
+    try:
+        for sched in (0, 2):
+            ops.gemm_ring(sched)
+            out = base.clone() if base is not None else torch.full((M, N), float("nan"), device=gpu_device)
+            ops.gemm(a, M, N, K, ws, out, addend=out if base is not None else None, **kw)
+            outs[sched] = out
+    finally:
+        ops.gemm_ring(old)
+    assert torch.equal(outs[0], outs[2])
+    assert rel_l2(outs[2].double().cpu(), ref.cpu()) < KTOL

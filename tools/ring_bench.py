@@ -40,9 +40,9 @@ for (m, n, k, odt, add, nseg) in shapes:
     out = torch.zeros(m, n, device=dev, dtype=odt)
     res = []
     for mode in (0, 2):
-        ops.gemm_bf16_ring(mode)
+        ops.gemm_ring(mode)
         res.append(timed(lambda: ops.gemm_bf16(a, m, n, k, ws, out, seg_mode=sm, addend=out if add else None)))
-    ops.gemm_bf16_ring(1)
+    ops.gemm_ring(1)
     fl = 2.0 * m * n * k
     print("M=%-7d N=%-5d K=%-5d %-5s %s  stream %7.1f us %6.0f TF | ring %7.1f us %6.0f TF  (x%.2f)"
           % (m, n, k, "bf16" if odt == BF else "f32", "add" if add else "   ", res[0] * 1e6, fl / res[0] / 1e12, res[1] * 1e6, fl / res[1] / 1e12, res[0] / res[1]))
