@@ -55,14 +55,17 @@ __device__ __forceinline__ void ring_glds16(const void *gsrc, unsigned lds_dst)
 template <int N>
 __device__ __forceinline__ void ring_wait()
 {
-    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-    else static_assert(N < 0, "unsupported count");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// a 4-byte global load the compiler does not see (so that it never puts its own, uncounted, vmcnt wait in front of the use): the
+// caller guarantees by the ring's counted waits that the value has arrived before it is read
+__device__ __forceinline__ float ring_gload(const float *ptr)
+{
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
 }
 
 // ET: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 bf16 (v_mfma_f32_32x32x16_bf16); NJ: accumulator columns per wave (tile = 256 x 128 NJ);
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     constexpr int RPW = 2 + NJ;                                    // LDS-DMA instructions per wave and step (2 x A, NJ x W)
     constexpr int NM = (ET ? 1 : 4) * 4 * NJ;                      // MFMAs of one slice
     constexpr int NSTORE = (OBF || GATE) ? 16 : 16 * NJ;           // 16-byte row stores per wave and tile in the epilogue
+    constexpr int NBIAS = GATE ? 2 : 4 * NJ;                       // bias loads per lane and tile (issued at the tile's start)
     extern __shared__ __attribute__((aligned(16))) char rlds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -221,6 +225,32 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
         int c_m0, c_n0;
         tile_coords(c_tile, c_m0, c_n0);
         clear_acc();
+        // bias values of this tile's columns: loaded HERE, behind the compiler's back -- a load it knows about gets an uncounted
+        // vmcnt(0) in front of its first use, i.e. a wait for every LDS-DMA in flight at the top of the epilogue.  The fourth counted
+        // wait of the K loop retires them (they are older than all but the last two steps' DMA).  Absent biases read A's first row.
+        const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
+        float braw[NJ][GATE ? 1 : LDM_MAX_SEG];
+        bool bhas[NJ][GATE ? 1 : LDM_MAX_SEG];
+        if constexpr (GATE) {
+            const int bidx = c_n0 + wn * 32 + r - seg_n * p.seg_len;
+            bhas[0][0] = p.bias[seg_n] != nullptr;
+            bhas[1][0] = p.bias2[seg_n] != nullptr;
+            braw[0][0] = ring_gload(bhas[0][0] ? p.bias[seg_n] + bidx : p.a);
+            braw[1][0] = ring_gload(bhas[1][0] ? p.bias2[seg_n] + bidx : p.a);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = c_n0 + wn * 32 * NJ + j * 32 + r;
+                const int bidx = (p.seg_mode == LDM_SEG_N) ? col - seg_n * p.seg_len : col;
+                const bool ksum = p.seg_mode == LDM_SEG_K;
+#pragma unroll
+                for (int sg = 0; sg < LDM_MAX_SEG; ++sg) {
+                    const float *base = ksum ? p.bias[sg] : (sg == 0 ? p.bias[seg_n] : nullptr);
+                    bhas[j][sg] = base != nullptr;
+                    braw[j][sg] = ring_gload(base ? base + bidx : p.a);
+                }
+            }
+        }
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt, ++s) {
             const char *st_cur = rlds + (s & (RNS - 1)) * RSTAGE, *st_nxt = rlds + ((s + 1) & (RNS - 1)) * RSTAGE;
@@ -237,8 +267,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
             // the previous tile's NSTORE row stores are also younger than the DMA waited for (they were issued after the DMA of the
             // tile's first three steps): counting them in keeps the wave from waiting out the whole chip's synchronised store burst
             // (all workgroups finish their equally long tiles together: 32 k cycles per tile before this).
-            if (kt < 3 && c_tile > 0 && nk >= 3) ring_wait<2 * RPW + NSTORE>();
-            else ring_wait<2 * RPW>();
+            // The tile's NBIAS bias loads are younger than that DMA in the same three steps.
+            if (kt < 3 && nk >= 3) {
+                if (c_tile > 0) ring_wait<2 * RPW + NSTORE + NBIAS>();
+                else ring_wait<2 * RPW + NBIAS>();
+            } else {
+                ring_wait<2 * RPW>();
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -256,33 +291,22 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
         }
 
         // ---- epilogue of this tile ----------------------------------------------------------------------------------------------
-        const int seg_n = (p.seg_mode == LDM_SEG_N) ? c_n0 / p.seg_len : 0;
+        if (nk < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // short tiles: the K loop's waits did not cover the bias loads
         float b1[NJ], b2 = 0.f;
-#if defined(LDM_RING_PROBE) && LDM_RING_PROBE == 2       // probe build: no bias loads
-        for (int j = 0; j < NJ; ++j) b1[j] = 0.f;
-        if constexpr (false) {
-#else
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int sg = 0; sg < (GATE ? 1 : LDM_MAX_SEG); ++sg) {
+                asm volatile("" : "+v"(braw[j][sg]));                            // keeps every use of the values below the K loop
+                braw[j][sg] = bhas[j][sg] ? braw[j][sg] : 0.f;
+            }
         if constexpr (GATE) {
-#endif
-            const int col = c_n0 + wn * 32 + r;
-            const int bidx = col - seg_n * p.seg_len;
-            b1[0] = p.bias[seg_n] ? p.bias[seg_n][bidx] : 0.f;
+            b1[0] = braw[0][0];
             b1[1] = 0.f;
-            b2 = p.bias2[seg_n] ? p.bias2[seg_n][bidx] : 0.f;
+            b2 = braw[1][0];
         } else {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = c_n0 + wn * 32 * NJ + j * 32 + r;
-                const int bidx = (p.seg_mode == LDM_SEG_N) ? col - seg_n * p.seg_len : col;
-                const bool ksum = p.seg_mode == LDM_SEG_K;
-                float braw[LDM_MAX_SEG];
-#pragma unroll
-                for (int sg = 0; sg < LDM_MAX_SEG; ++sg) {
-                    const float *base = ksum ? p.bias[sg] : (sg == 0 ? p.bias[seg_n] : nullptr);
-                    braw[sg] = base ? base[bidx] : 0.f;
-                }
-                b1[j] = ((braw[0] + braw[1]) + braw[2]) + braw[3];
-            }
+            for (int j = 0; j < NJ; ++j) b1[j] = ((braw[j][0] + braw[j][1]) + braw[j][2]) + braw[j][3];
         }
         const long long orow0 = (long long)(c_m0 + wm * 128);
 #if defined(LDM_RING_PROBE) && LDM_RING_PROBE == 1       // probe build: no epilogue at all (results are not stored)
