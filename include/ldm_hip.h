@@ -128,8 +128,8 @@ int ldm_gemm_variant(int v);
 int ldm_gemm_wide_epilogue(int v);
 /* schedule of ldm_gemm_f32 / ldm_gemm_bf16 for rows-in / rows-out problems with M a multiple of 256 and N (and N-segments) a
  * multiple of 128: 1 (default) = the one-workgroup-per-CU ring kernel (256 x 256 / 256 x 128 tiles, four-stage LDS ring) when at
- * least 192 tiles exist, 0 = always the 128-row stream kernel, 2 = the ring kernel whenever the shape is legal.  Bit-identical
- * results; A/B and test knob.  Returns the previous setting (other v only queries). */
+ * least 192 tiles exist, 0 = always the 128-row stream kernel, 2 = the ring kernel whenever the shape is legal, 3 = like 2 on at
+ * most eight workgroups (tests: many tiles per workgroup).  Bit-identical results; A/B and test knob.  Returns the previous setting (other v only queries). */
 int ldm_gemm_ring(int v);
 
 /* hot-kernel timing for bench.py: when enabled every ldm_gemm_f32 launch is

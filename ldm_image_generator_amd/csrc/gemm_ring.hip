@@ -36,7 +36,8 @@ constexpr int RSTAGE = 32768;                // bytes per stage: A rows at 0, W 
 constexpr int RSCRATCH = 8 * 4096;           // epilogue scratch, 4 KiB per wave
 constexpr size_t RSMEM = (size_t)RNS * RSTAGE + RSCRATCH;      // 160 KiB: the whole LDS of a CU
 
-int g_ring = 1;                              // 0 off, 1 auto (large problems), 2 whenever the shape is legal (tests)
+int g_ring = 1;                              // 0 off, 1 auto (large problems), 2 whenever the shape is legal, 3 = 2 on at most 8 workgroups
+                                             // (tests: many tiles per workgroup out of small problems -- the stream across tile boundaries)
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -423,6 +424,7 @@ int ring_launch(const GemmP &p, hipStream_t st)
     const int ntm = p.M / RT, ntn = p.N / (GATE ? 128 : 128 * NJ);
     const int total = ntm * ntn;
     int grid = total < cus ? total : cus;
+    if (g_ring == 3 && grid > 8) grid = 8;
     if (grid > 8) grid &= ~7;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), RSMEM, st, p, ntm, ntn, total);
     return 1;
@@ -443,7 +445,7 @@ int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32)
     // auto: the tiles fill whole rounds of the CUs (one workgroup each: 384 tiles on 256 CUs ran 18 % BEHIND the stream kernel, 768
     // ahead of it), a tile is at least 8 steps long, and -- fp32 only -- an in-place addend comes with K >= 384 (its loads are not
     // prefetched under the last K-step as in the stream kernel: out-projections at K = 128 / 256 lost 6 %)
-    const bool any = g_ring == 2;
+    const bool any = g_ring >= 2;
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
@@ -468,7 +470,7 @@ int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32)
 extern "C" int ldm_gemm_ring(int v)
 {
     const int old = g_ring;
-    if (v >= 0 && v <= 2) g_ring = v;
+    if (v >= 0 && v <= 3) g_ring = v;
     return old;
 }
 

@@ -63,6 +63,9 @@ def test_gemm_bf16(gpu_device, M, N, K, nseg, seg_mode, act, addend, out16):
     (2048, 2048, 1024, 1, 0, 0, False, True),
     (65536, 512, 512, 1, 0, 3, True, False),       # 512 tiles on 256 workgroups: the stream across tile boundaries, leaky relu
     (16384, 256, 192, 1, 0, 0, False, True),       # six steps per tile
+    (4096, 512, 64, 1, 0, 1, False, True),         # schedule 3 (eight workgroups): 4 tiles per workgroup of TWO steps, bf16 out
+    (6144, 256, 192, 3, 1, 0, True, False),        # ... K-segments of 64 (two steps each), addend, 3 tiles per workgroup
+    (8192, 768, 128, 3, 0, 0, False, False),       # ... N-segments, fp32 out, 12 tiles per workgroup of four steps
 ])
 def test_gemm_bf16_ring_kernel_bit_identical_to_stream_kernel(gpu_device, M, N, K, nseg, seg_mode, act, addend, out16):
     """256 x 256 four-stage ring kernel (gemm_bf16_ring.hip) == 128 x 128 stream kernel, bit for bit (same 16-k slices in the
@@ -84,14 +87,14 @@ def test_gemm_bf16_ring_kernel_bit_identical_to_stream_kernel(gpu_device, M, N, 
     outs = {}
     old = ops.gemm_ring(1)
     try:
-        for mode in (0, 2):
+        for mode in (0, 2, 3):
             ops.gemm_ring(mode)
             out = base.clone() if addend else torch.full((M, N), float("nan"), device=gpu_device, dtype=BF if out16 else torch.float32)
             ops.gemm_bf16(a, M, N, K, ws, out, biases=biases, seg_mode=seg_mode, act=act, slope=0.2, addend=out if addend else None)
             outs[mode] = out
     finally:
         ops.gemm_ring(old)
-    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
     if M * N * K <= 2 ** 33:
         ref = a.double() @ wfull.t() + bfull
         if act == 1:

@@ -454,6 +454,10 @@ def test_gemm_split_k_small_m(ops, gpu_device, M, N, K, mode):
     (512, 1536, 512, "gate"),
     (65536, 256, 256, "lrelu"),         # 256 tiles on 256 workgroups ... and
     (131072, 128, 384, "kseg128"),      # ... 512 tiles of 256 x 128: the stream across tile boundaries, K-segments of 128
+    (4096, 768, 96, "gate"),            # schedule 3 (eight workgroups): 12 gated tiles per workgroup of six steps each
+    (8192, 384, 32, "nseg128"),         # ... 12 tiles of TWO steps (shorter than the ring)
+    (4096, 512, 160, "plain"),          # ... ten steps per tile, 4 tiles per workgroup
+    (6144, 256, 96, "kseg"),            # ... K-segments of 32 (two steps each), addend, 3 tiles per workgroup
 ])
 def test_gemm_ring_kernel_fp32_bit_identical_to_stream_kernel(ops, gpu_device, M, N, K, mode):
     """One-workgroup-per-CU ring kernel (gemm_ring.hip, exact fp32) == the 128-row stream kernel bit for bit (same k pairing and
@@ -495,12 +499,12 @@ def test_gemm_ring_kernel_fp32_bit_identical_to_stream_kernel(ops, gpu_device, M
     outs = {}
     old = ops.gemm_ring(1)
     try:
-        for sched in (0, 2):
+        for sched in (0, 2, 3):
             ops.gemm_ring(sched)
             out = base.clone() if base is not None else torch.full((M, N), float("nan"), device=gpu_device)
             ops.gemm(a, M, N, K, ws, out, addend=out if base is not None else None, **kw)
             outs[sched] = out
     finally:
         ops.gemm_ring(old)
-    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
     assert rel_l2(outs[2].double().cpu(), ref.cpu()) < KTOL

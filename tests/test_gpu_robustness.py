@@ -118,3 +118,27 @@ def test_sharded_sampling_with_eta_equals_unsharded(gpu_device):
     b = d.sample((2, 8, 16, 16), seed=3, num_steps=4, eta=0.7, x_init=xT[2:], progress=False, shard=(4, 2, 4))
     assert rel_l2(torch.cat([a, b]).cpu(), full.cpu()) < 5e-6
     assert not torch.equal(a, b)
+
+
+def test_full_width_unet_forward_ring_kernel_bit_identical(gpu_device):
+    """The one-workgroup-per-CU ring kernel inside the whole network: default-width UNet, B = 16 (stage-0 gate: 192 gated tiles, the
+    auto rule's threshold), schedules 0 (stream kernel only), 1 (auto) and 2 (ring wherever the shape is legal: QKV, K-segment GEMM with
+    in-place addend, out-projection, all four stages) give the same bits, through the native executor and the Python orchestration."""
+    from ldm_image_generator_amd import ops
+    from ldm_image_generator_amd.unet import UNet
+    net = formula(UNet()).eval()
+    x = torch.randn(16, 8, 32, 32, generator=torch.Generator().manual_seed(11)).cuda()
+    t = torch.randint(0, 1000, (16,), generator=torch.Generator().manual_seed(12)).cuda()
+    outs = {}
+    old = ops.gemm_ring(1)
+    try:
+        for native in (True, False):
+            for mode in (0, 1, 2):
+                ops.gemm_ring(mode)
+                outs[(native, mode)] = _fwd(net, x, t, native)
+    finally:
+        ops.gemm_ring(old)
+    ref = outs[(True, 0)]
+    assert bool(torch.isfinite(ref).all())
+    for key, y in outs.items():
+        assert torch.equal(y, ref), key
