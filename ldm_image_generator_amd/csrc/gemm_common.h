@@ -344,18 +344,23 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
         unsigned short *ob16 = pass == 0 ? obase16 : (unsigned short *)(pass == 1 ? p.out2 : p.out3) + oelem;
+        // gate backward: the saved pre-activations of this lane's row pieces, half a strip (2 TN pieces) at a time.  The loads of half
+        // hh + 1 are issued BEFORE half hh is stored: loads issued behind stores cannot retire (vmcnt is in order) until those stores
+        // are acknowledged -- a write round trip per strip with the loads at the strip's top.
+        constexpr int HP = 2 * TN;                                        // row pieces per half strip
+        u32x2_t ga[2][HP], gb[2][HP];
+        auto load_ab = [&](int hh) {
+#pragma unroll
+            for (int k = 0; k < HP; ++k) {
+                int roff = (hh >> 1) * 32 + ((hh & 1) * HP + k) * RPI;
+                if (!full && row0 + roff >= p.M) roff = p.M - 1 - row0;          // clamp (the result is not stored)
+                ga[hh & 1][k] = *(const u32x2_t *)((const unsigned short *)p.in2 + oelem + (long long)roff * ldo_);
+                gb[hh & 1][k] = *(const u32x2_t *)((const unsigned short *)p.in3 + oelem + (long long)roff * ldo_);
+            }
+        };
+        if (gate_bwd) load_ab(0);
 #pragma unroll
         for (int im = 0; im < TM; ++im) {
-            u32x2_t ga[4 * TN], gb[4 * TN];                 // gate backward: the saved pre-activations of this lane's row pieces
-            if (gate_bwd) {
-#pragma unroll
-                for (int k = 0; k < 4 * TN; ++k) {
-                    int roff = im * 32 + k * RPI;
-                    if (!full && row0 + roff >= p.M) roff = p.M - 1 - row0;          // clamp (the result is not stored)
-                    ga[k] = *(const u32x2_t *)((const unsigned short *)p.in2 + oelem + (long long)roff * ldo_);
-                    gb[k] = *(const u32x2_t *)((const unsigned short *)p.in3 + oelem + (long long)roff * ldo_);
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
 #pragma unroll
@@ -378,6 +383,8 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
                 }
 #pragma unroll
             for (int k = 0; k < 4 * TN; ++k) {
+                const int hh = 2 * im + k / HP;                       // half strip of this piece
+                if (gate_bwd && k % HP == 0 && hh + 1 < 2 * TM) load_ab(hh + 1);
                 const int off = (TN == 1) ? k * 1024 : (k >> 1) * 2048 + (k & 1) * 64;
                 f32x4 v = *(const f32x4 *)(rd + off);
                 if (use_pre) {
@@ -391,7 +398,7 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
                             float da[4], db[4];
 #pragma unroll
                             for (int cix = 0; cix < 4; ++cix) {
-                                const unsigned wa = ga[k][cix >> 1], wb = gb[k][cix >> 1];
+                                const unsigned wa = ga[hh & 1][k % HP][cix >> 1], wb = gb[hh & 1][k % HP][cix >> 1];
                                 const float av = __uint_as_float((cix & 1) ? (wa & 0xFFFF0000u) : (wa << 16));
                                 const float bv = __uint_as_float((cix & 1) ? (wb & 0xFFFF0000u) : (wb << 16));
                                 da[cix] = v[cix] * fmaxf(bv, 0.f);
