@@ -226,6 +226,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
         int c_m0, c_n0;
         tile_coords(c_tile, c_m0, c_n0);
         clear_acc();
+#ifdef LDM_RING_STAMP      // probe build (tools): cycle stamps of workgroup 0 / wave 0 into the buffer passed as bias2[0] of a plain problem
+        long long *stamps = (!GATE && blockIdx.x == 0 && wave == 0 && lane == 0) ? (long long *)p.bias2[0] : nullptr;
+        if (stamps && c_tile < 16) stamps[c_tile * 4 + 0] = (long long)__builtin_amdgcn_s_memtime();
+        if (stamps && (c_tile == 0 || c_tile == my_tiles - 1)) {
+            stamps[200 + (c_tile ? 2 : 0)] = (long long)__builtin_amdgcn_s_memtime();
+            stamps[201 + (c_tile ? 2 : 0)] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
         // bias values of this tile's columns: loaded HERE, behind the compiler's back -- a load it knows about gets an uncounted
         // vmcnt(0) in front of its first use, i.e. a wait for every LDS-DMA in flight at the top of the epilogue.  The fourth counted
         // wait of the K loop retires them (they are older than all but the last two steps' DMA).  Absent biases read A's first row.
@@ -289,7 +297,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                 __builtin_amdgcn_sched_barrier(0);
             }
             issue_advance(live);
+#ifdef LDM_RING_STAMP
+            if (stamps && c_tile == 1 && kt < 32) stamps[64 + kt] = (long long)__builtin_amdgcn_s_memtime();
+#endif
         }
+#ifdef LDM_RING_STAMP
+        if (stamps && c_tile < 16) stamps[c_tile * 4 + 1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
 
         // ---- epilogue of this tile ----------------------------------------------------------------------------------------------
         if (nk < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // short tiles: the K loop's waits did not cover the bias loads
@@ -403,6 +417,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
             else if (p.act == LDM_ACT_LRELU) run(std::integral_constant<int, LDM_ACT_LRELU>{});
             else run(std::integral_constant<int, LDM_ACT_NONE>{});
         }
+#ifdef LDM_RING_STAMP
+        if (stamps && c_tile < 16) stamps[c_tile * 4 + 2] = (long long)__builtin_amdgcn_s_memtime();
+        if (!GATE && wave == 0 && lane == 0 && p.bias2[0]) {                     // every workgroup: realtime at its first tile's start and at its last tile's end
+            long long *all = (long long *)p.bias2[0];
+            if (c_tile == 0) all[256 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+            if (c_tile == my_tiles - 1) all[257 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
     }
     // the trailing (dummy) DMA must have landed before the workgroup's LDS is handed to the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
