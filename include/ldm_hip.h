@@ -333,6 +333,22 @@ int ldm_vq_loss_f32(const float *x, const float *e, long long n, float *loss, vo
 int ldm_vq_loss_bwd_f32(const float *x, const float *e, const long long *idx, const float *gscale, float *dx, float *demb, long long M, int N, int D,
                         void *stream);
 
+/* ---- VAE Decoder backward (vae.py:54-66,99-132), the pieces that are not GEMMs --------------------------------------
+ * The dense 3x3 data gradient is ldm_gemm_f32 (LDM_A_CONV3X3) on the flipped, in/out-swapped filter, its weight gradient
+ * ldm_gemm_tn_f32 of dy against ldm_im2col3x3_f32(x); the ConvTranspose 2x2 gradients are plain GEMMs on the
+ * ldm_space_to_depth2_f32 image of the fine gradient. */
+/* dx = dy * (y > 0 ? 1 : slope) with y the activated output of F.leaky_relu (vae.py:62,64); n % 4 == 0 */
+int ldm_lrelu_bwd_f32(const float *dy, const float *y, float *dx, long long n, float slope, void *stream);
+/* out[p][tap * C + c] = x[p + tap][c], zero outside the image; x [B*H*W, C] channels-last rows, out [B*H*W, 9*C] */
+int ldm_im2col3x3_f32(const float *x, float *out, int B, int H, int W, int C, void *stream);
+/* out[(b, y, x)][(dy*2 + dx)*C + c] = fine[(b, 2y + dy, 2x + dx)][c]; H, W = the COARSE size, fine [B*2H*2W, C], out [B*H*W, 4*C] */
+int ldm_space_to_depth2_f32(const float *fine, float *out, int B, int H, int W, int C, void *stream);
+/* backward of ldm_rgb_head_f32 (to_rgb 1x1 conv + bilinear x2 accumulation of the previous stage's RGB, vae.py:106-107,131):
+ * drgb [B, 3, H, W] (NCHW); drows [B*H*W, C] = (accumulate ? drows : 0) + drgb . w; dprev [B, 3, H/2, W/2] (zeroed by the caller,
+ * or NULL) += adjoint of the bilinear x2; dw [3, C] and db [3] (zeroed by the caller) += the to_rgb weight / bias gradient */
+int ldm_rgb_head_bwd_f32(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *dprev, float *dw,
+                         float *db, int B, int H, int W, int C, void *stream);
+
 /* Grouped 3x3 conv of unet.py:30,44 (32 in / 32 out per group, zero pad 1) with bf16 operands, fp32 accumulate:
  * out[m, :] = conv(x)[m, :] (+ bias) (+ addend[m, :]);  x [B*H*W, C] bf16, w [C][9][32] bf16 (ldm_gemm_f32's packed grouped
  * layout: output channel, tap, input channel), bias [C] / addend [B*H*W, C] fp32 or NULL, out fp32 (may alias addend).

@@ -147,6 +147,11 @@ SIGNATURES = {
     "ldm_vq_embed_f32": (_I, [_P, _P, _P, _L, _I, _P]),
     "ldm_vq_loss_f32": (_I, [_P, _P, _L, _P, _P]),
     "ldm_vq_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    # VAE Decoder backward
+    "ldm_lrelu_bwd_f32": (_I, [_P, _P, _P, _L, _F, _P]),
+    "ldm_im2col3x3_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_space_to_depth2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_rgb_head_bwd_f32": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_multi_cast_table_bytes": (ctypes.c_size_t, [_I]),
     "ldm_multi_cast_bf16": (_I, [ctypes.POINTER(CastJob), _I, _P, _I, ctypes.POINTER(_L), _P]),
     "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -1,0 +1,171 @@
+// Backward pieces of the VAE Decoder (vae.py:54-66,99-132) that are not GEMMs: leaky-ReLU gradient, row-major im2col for the dense 3x3
+// weight gradient, space-to-depth for the ConvTranspose 2x2 gradients, and the to_rgb + bilinear x2 head.  The GEMM-shaped
+// gradients reuse ldm_gemm_f32 (data gradients: the implicit 3x3 GEMM on flipped / transposed filters) and ldm_gemm_tn_f32.
+#include "common.h"
+
+namespace {
+
+inline unsigned vb_blocks(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// dx = dy * (y > 0 ? 1 : slope); y is the ACTIVATED output (slope > 0: its sign is the pre-activation's)
+__global__ void lrelu_bwd_kernel(const f32x4 *__restrict__ dy, const f32x4 *__restrict__ y, f32x4 *__restrict__ dx, long long n4, float slope)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 g = dy[i], v = y[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? g[e] : g[e] * slope;
+    dx[i] = o;
+}
+
+// out[p][tap * C + c] = x[p + tap][c] (zero outside the image): the A operand of dW = dY^T . im2col(X)
+__global__ void im2col3x3_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__ out, int B, int H, int W, int C4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece of one (pixel, tap)
+    const long long total = (long long)B * H * W * 9 * C4;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const long long r = i / C4;
+    const int tap = (int)(r % 9);
+    const long long p = r / 9;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const bool ok = (unsigned)(yy + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W;
+    out[i] = ok ? x[(p + (long long)dy * W + dx) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// out[(b, y, x)][(dy * 2 + dx) * C + c] = fine[(b, 2 y + dy, 2 x + dx)][c]   (H, W: the COARSE size)
+__global__ void space_to_depth2_kernel(const f32x4 *__restrict__ fine, f32x4 *__restrict__ out, int B, int H, int W, int C4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * 4 * C4;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const long long r = i / C4;
+    const int q = (int)(r & 3);
+    const long long p = r >> 2;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const long long b = p / ((long long)W * H);
+    const long long fp = (b * 2 * H + 2 * yy + (q >> 1)) * 2 * W + 2 * xx + (q & 1);
+    out[i] = fine[fp * C4 + c4];
+}
+
+// rgb head backward, per pixel: drows[p][c] (+)= sum_j drgb[b][j][pix] w[j][c]; and the adjoint of the bilinear x2 accumulation
+// (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False), vae.py:131) scattered into dprev with atomics
+__global__ __launch_bounds__(256) void rgb_head_bwd_kernel(const float *__restrict__ drgb, const float *__restrict__ w, float *__restrict__ drows,
+                                                           float *__restrict__ dprev, int B, int H, int W, int C, int accumulate)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (long long)B * H * W) return;
+    const int HW = H * W;
+    const long long b = row / HW;
+    const int pix = (int)(row - b * HW);
+    const float g0 = drgb[(b * 3 + 0) * HW + pix], g1 = drgb[(b * 3 + 1) * HW + pix], g2 = drgb[(b * 3 + 2) * HW + pix];
+    f32x4 *dr = (f32x4 *)(drows + row * C);
+    for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
+        const f32x4 w0 = ((const f32x4 *)w)[c4], w1 = ((const f32x4 *)(w + C))[c4], w2 = ((const f32x4 *)(w + 2 * C))[c4];
+        f32x4 o = accumulate ? dr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += (g0 * w0[e] + g1 * w1[e]) + g2 * w2[e];
+        dr[c4] = o;
+    }
+    if (dprev && lane < 12) {                                 // 3 channels x 4 source pixels
+        const int y = pix / W, xx = pix - y * W;
+        const int PH = H >> 1, PW = W >> 1;
+        float sy = 0.5f * (float)y - 0.25f, sx = 0.5f * (float)xx - 0.25f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < PH - 1 ? 1 : 0), x1 = x0 + (x0 < PW - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const int j = lane >> 2, corner = lane & 3;
+        const float wy = (corner >> 1) ? ly : 1.f - ly, wx = (corner & 1) ? lx : 1.f - lx;
+        const int py = (corner >> 1) ? y1 : y0, px = (corner & 1) ? x1 : x0;
+        const float g = j == 0 ? g0 : (j == 1 ? g1 : g2);
+        atomicAdd(dprev + (b * 3 + j) * PH * PW + py * PW + px, g * wy * wx);
+    }
+}
+
+// dw[j][c] += sum_p drgb[p][j] rows[p][c], db[j] += sum_p drgb[p][j]  over a slab of pixels per block (atomics into zeroed buffers)
+__global__ __launch_bounds__(256) void rgb_head_wgrad_kernel(const float *__restrict__ drgb, const float *__restrict__ rows, float *__restrict__ dw,
+                                                             float *__restrict__ db, int B, int HW, int C, int slab)
+{
+    const long long total = (long long)B * HW;
+    const long long p0 = (long long)blockIdx.x * slab;
+    const long long p1 = p0 + slab < total ? p0 + slab : total;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (long long p = p0; p < p1; ++p) {
+            const long long b = p / HW;
+            const int pix = (int)(p - b * HW);
+            const float g0 = drgb[(b * 3 + 0) * HW + pix], g1 = drgb[(b * 3 + 1) * HW + pix], g2 = drgb[(b * 3 + 2) * HW + pix];
+            const float v = rows[p * C + c];
+            a0 = fmaf(g0, v, a0);
+            a1 = fmaf(g1, v, a1);
+            a2 = fmaf(g2, v, a2);
+            s0 += g0;
+            s1 += g1;
+            s2 += g2;
+        }
+        atomicAdd(dw + c, a0);
+        atomicAdd(dw + C + c, a1);
+        atomicAdd(dw + 2 * C + c, a2);
+        if (c == 0) {
+            atomicAdd(db + 0, s0);
+            atomicAdd(db + 1, s1);
+            atomicAdd(db + 2, s2);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ldm_lrelu_bwd_f32(const float *dy, const float *y, float *dx, long long n, float slope, void *stream)
+{
+    LDM_REQUIRE(dy && y && dx && n > 0 && n % 4 == 0, "ldm_lrelu_bwd_f32: bad arguments (n %% 4 == 0)");
+    LDM_REQUIRE(ldm_aligned16(dy) && ldm_aligned16(y) && ldm_aligned16(dx), "ldm_lrelu_bwd_f32: unaligned pointer");
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(vb_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)dy, (const f32x4 *)y, (f32x4 *)dx,
+                       n / 4, slope);
+    LDM_CHECK_LAUNCH("ldm_lrelu_bwd_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_im2col3x3_f32(const float *x, float *out, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ldm_im2col3x3_f32: bad arguments (C %% 4 == 0)");
+    LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(out), "ldm_im2col3x3_f32: unaligned pointer");
+    const long long total = (long long)B * H * W * 9 * (C / 4);
+    LDM_REQUIRE(total / 256 < 0x7fffffffLL, "ldm_im2col3x3_f32: problem too large");
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(vb_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (f32x4 *)out, B, H, W, C / 4);
+    LDM_CHECK_LAUNCH("ldm_im2col3x3_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_space_to_depth2_f32(const float *fine, float *out, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(fine && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ldm_space_to_depth2_f32: bad arguments (C %% 4 == 0)");
+    LDM_REQUIRE(ldm_aligned16(fine) && ldm_aligned16(out), "ldm_space_to_depth2_f32: unaligned pointer");
+    const long long total = (long long)B * H * W * 4 * (C / 4);
+    LDM_REQUIRE(total / 256 < 0x7fffffffLL, "ldm_space_to_depth2_f32: problem too large");
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(vb_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)fine, (f32x4 *)out, B, H, W,
+                       C / 4);
+    LDM_CHECK_LAUNCH("ldm_space_to_depth2_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_rgb_head_bwd_f32(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *dprev, float *dw,
+                                    float *db, int B, int H, int W, int C, void *stream)
+{
+    LDM_REQUIRE(drgb && w && rows && drows && dw && db, "ldm_rgb_head_bwd_f32: null pointer");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (!dprev || (H % 2 == 0 && W % 2 == 0)), "ldm_rgb_head_bwd_f32: bad shape");
+    LDM_REQUIRE(ldm_aligned16(w) && ldm_aligned16(drows), "ldm_rgb_head_bwd_f32: unaligned pointer");
+    const long long rowsn = (long long)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rgb_head_bwd_kernel, dim3(vb_blocks(rowsn, 4)), dim3(256), 0, st, drgb, w, drows, dprev, B, H, W, C, accumulate);
+    const int slab = 256;
+    hipLaunchKernelGGL(rgb_head_wgrad_kernel, dim3(vb_blocks(rowsn, slab)), dim3(256), 0, st, drgb, rows, dw, db, B, H * W, C, slab);
+    LDM_CHECK_LAUNCH("ldm_rgb_head_bwd_f32");
+    return LDM_OK;
+}

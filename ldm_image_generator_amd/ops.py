@@ -15,7 +15,7 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
            "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "prof_read_class", "prof_read_bytes", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
-           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue", "gemm_ring", "gemm_tn", "gconv3x3_wgrad",
+           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "gemm_variant", "gemm_wide_epilogue", "gemm_ring", "lrelu_bwd", "im2col3x3", "space_to_depth2", "rgb_head_bwd", "gemm_tn", "gconv3x3_wgrad",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
 
@@ -484,6 +484,31 @@ def vq_loss(x_rows, e_rows):
     loss = torch.empty(1, device=x_rows.device, dtype=torch.float32)
     _call("ldm_vq_loss_f32", _dev(x_rows, "x"), _dev(e_rows, "e"), x_rows.numel(), _dev(loss, "loss"))
     return loss
+
+
+def lrelu_bwd(dy, y, slope=0.01):
+    """dy * (y > 0 ? 1 : slope), y = the activated output."""
+    dx = torch.empty_like(dy)
+    _call("ldm_lrelu_bwd_f32", _dev(dy, "dy"), _dev(y, "y"), _dev(dx, "dx"), dy.numel(), float(slope))
+    return dx
+
+
+def im2col3x3(rows, B, H, W, C):
+    out = torch.empty(B * H * W, 9 * C, device=rows.device, dtype=torch.float32)
+    _call("ldm_im2col3x3_f32", _dev(rows, "rows"), _dev(out, "out"), B, H, W, C)
+    return out
+
+
+def space_to_depth2(fine, B, H, W, C):
+    """fine [B*2H*2W, C] -> [B*H*W, 4C] ((dy, dx, c) minor)."""
+    out = torch.empty(B * H * W, 4 * C, device=fine.device, dtype=torch.float32)
+    _call("ldm_space_to_depth2_f32", _dev(fine, "fine"), _dev(out, "out"), B, H, W, C)
+    return out
+
+
+def rgb_head_bwd(drgb, w, rows, drows, accumulate, dprev, dw, db, B, H, W, C):
+    _call("ldm_rgb_head_bwd_f32", _dev(drgb, "drgb"), _dev(w, "w"), _dev(rows, "rows"), _dev(drows, "drows"), int(bool(accumulate)),
+          _opt(dprev, "dprev"), _dev(dw, "dw"), _dev(db, "db"), B, H, W, C)
 
 
 def vq_loss_bwd(x_rows, e_rows, idx, gscale, n_emb):

@@ -9,7 +9,8 @@ bilinear RGB accumulation are one fused HBM-bound kernel per stage.
 
 ``Encoder`` (latent pre-encoding for train_ldm.py) reuses the same kernels.  SURVEY 8f.4 (VAE training) is started
 with its integer part: ``VectorQuantizer`` (quantize with the reference's indices, embed, the two-sided L1 loss with gradients) and
-the forward of ``VAE.calclate_loss``; the ``Discriminator`` and the Encoder / Decoder backward are not provided.
+the forward of ``VAE.calclate_loss``; ``Decoder`` is differentiable (``vae_train.DecoderFunction``: parameter gradients and dL/dz,
+pinned against the reference's autograd); the ``Discriminator`` and the Encoder backward are not provided.
 """
 import torch
 import torch.nn as nn
@@ -166,6 +167,10 @@ class Decoder(nn.Module):
 
     def forward(self, x):
         """vae.py:122-132: z [B, latent, h, w] -> RGB [B, 3, 8h, 8w] (NCHW)."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: same kernels + tape, hand-written backward (vae_train.py); wrap pure inference in torch.no_grad()
+            from .vae_train import DecoderFunction
+            return DecoderFunction.apply(self, x, *[p for p in self.parameters() if p.requires_grad])
         b, cz, h, w = x.shape
         dev = x.device
         c0 = self.input_layer.weight.shape[0]
@@ -230,8 +235,8 @@ class VectorQuantizer(nn.Module):
 
 class VAE(nn.Module):
     """vae.py:30-52.  ``encode`` / ``decode`` are the sampling path; ``calclate_loss`` (sic) is the FORWARD of the VAE training
-    objective (the backward through Encoder / Decoder -- dense 3x3, ConvTranspose and bilinear gradients -- is not built, so the
-    call is only valid under ``torch.no_grad()``)."""
+    objective (the Decoder has its backward, ``vae_train.py``; the Encoder's -- avg-pool + 1x1 + the same dense 3x3 pieces -- is not
+    wired yet, so the call as a whole is only valid under ``torch.no_grad()``)."""
 
     def __init__(self, encoder, decoder, quantizer):
         super().__init__()

@@ -1,0 +1,136 @@
+"""Backward of the VAE ``Decoder`` (vae.py:99-132: stem 1x1, ConvTranspose 2x2 up-samplings, ResBlocks of dense 3x3 convs with
+leaky ReLU, to_rgb heads accumulated through bilinear x2) on the HIP path -- SURVEY f4 / the VAE training objective's decoder side.
+
+ONE ``torch.autograd.Function`` for the whole decoder, like ``train.UNetFunction``: the forward runs the inference kernels and keeps
+the tape (per ResBlock: its input, the activated hidden ``y1`` and the activated branch ``t2``), the backward walks it in reverse:
+
+* dense 3x3 data gradient  = the same implicit-GEMM conv on the flipped, in/out-swapped filter (``ldm_gemm_f32``, ``A_CONV3X3``);
+* dense 3x3 weight gradient = ``dy^T . im2col(x)`` (``ldm_im2col3x3_f32`` + the TN / NT weight-gradient GEMMs of ``train.py``);
+* ConvTranspose 2x2 (stride 2) = a plain GEMM per fine-pixel parity: gradients through ``ldm_space_to_depth2_f32``;
+* leaky ReLU: ``ldm_lrelu_bwd_f32`` on the ACTIVATED outputs (slope > 0 keeps the sign);
+* to_rgb + bilinear x2 accumulation: ``ldm_rgb_head_bwd_f32``.
+
+fp32 throughout (the reference trains the VAE under autocast; this is the exact-fp32 statement of the same graph)."""
+import torch
+
+from . import ops
+from .modules import w2d
+from .train import _Rows, grad_weight_rows
+
+SLOPE = 0.01            # F.leaky_relu's default negative_slope (vae.py:62,64)
+
+
+def _pack3x3(w):        # [Cout, Cin, 3, 3] -> [Cout][tap][Cin]
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
+
+
+def _pack3x3_dgrad(w):  # filter of the data gradient: [Cin][tap'][Cout] with tap' = the mirrored tap
+    return w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], 9 * w.shape[0]).contiguous()
+
+
+def _conv(rows, shape, packed, bias, cin, cout, act, addend=None):
+    b, h, w = shape
+    out = torch.empty(rows.shape[0], cout, device=rows.device, dtype=torch.float32)
+    ops.gemm(rows, rows.shape[0], cout, 9 * cin, [packed], out, lda=cin, ldw=9 * cin, biases=None if bias is None else [bias],
+             act=act, slope=SLOPE, addend=addend, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=cin)
+    return out
+
+
+def _conv_grads(dy, x, shape, conv, grads):
+    """weight / bias gradient of one dense 3x3 conv from the gradient at its pre-activation and its input rows."""
+    b, h, w = shape
+    cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+    dyr = _Rows(dy)
+    dw = grad_weight_rows(dyr, _Rows(ops.im2col3x3(x, b, h, w, cin)), dy.shape[0])          # [Cout, 9 Cin]
+    grads[conv.weight] = dw.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+    grads[conv.bias] = dyr.colsum().clone()
+
+
+class DecoderFunction(torch.autograd.Function):
+    """vae.py:122-132 forward + backward.  ``params`` only anchors the graph."""
+
+    @staticmethod
+    def forward(fctx, dec, z, *params):
+        from torch import nn
+        b, cz, h, w = z.shape
+        dev = z.device
+        z = z.contiguous().float()
+        c0 = dec.input_layer.weight.shape[0]
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(z, w2d(dec.input_layer), dec.input_layer.bias.detach(), rows, b, cz, h * w, c0)
+        tape, rgb = [], None
+        for i, (up, stage) in enumerate(zip(dec.upsamples, dec.stages)):
+            rec = dict(up=None, blocks=[])
+            if not isinstance(up, nn.Identity):
+                cin, cout = up.weight.shape[0], up.weight.shape[1]
+                packed = up.weight.detach().permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous()      # [(dy, dx, co)][ci]
+                fine = torch.empty(b * 4 * h * w, cout, device=dev, dtype=torch.float32)
+                ops.gemm(rows, b * h * w, 4 * cout, cin, [packed], fine, biases=[up.bias.detach()], ldo=cout, o_mode=ops.O_CONVT2X2,
+                         out_hw=(h, w), cout=cout)
+                rec["up"] = dict(conv=up, x=rows, packed=packed, hw=(h, w))
+                rows, h, w = fine, 2 * h, 2 * w
+            shape = (b, h, w)
+            c = rows.shape[1]
+            for blk in stage.layers:
+                y1 = _conv(rows, shape, _pack3x3(blk.c1.weight), blk.c1.bias.detach(), c, c, ops.ACT_LRELU)
+                t2 = _conv(y1, shape, _pack3x3(blk.c2.weight), blk.c2.bias.detach(), c, c, ops.ACT_LRELU)
+                rec["blocks"].append(dict(blk=blk, x=rows, y1=y1, t2=t2))
+                rows = ops.add_(t2.clone(), rows)                                   # x + lrelu(c2(lrelu(c1(x))))  (vae.py:60-66)
+            new_rgb = torch.empty(b, 3, h, w, device=dev, dtype=torch.float32)
+            ops.rgb_head(rows, w2d(stage.to_rgb), stage.to_rgb.bias.detach(), rgb, new_rgb, b, h, w, c)
+            rec.update(stage=stage, rows=rows, shape=shape, has_prev=rgb is not None)
+            tape.append(rec)
+            rgb = new_rgb
+        fctx.dec, fctx.tape, fctx.z, fctx.params = dec, tape, z, params
+        return rgb
+
+    @staticmethod
+    def backward(fctx, dout):
+        dec, tape, z = fctx.dec, fctx.tape, fctx.z
+        dev = dout.device
+        grads = {}
+        drgb = dout.contiguous().float()
+        drows = None                                                  # gradient w.r.t. the stage's output rows coming from the finer stage
+        for rec in reversed(tape):
+            stage, rows, (b, h, w) = rec["stage"], rec["rows"], rec["shape"]
+            c = rows.shape[1]
+            dw_rgb = torch.zeros(3, c, device=dev, dtype=torch.float32)
+            db_rgb = torch.zeros(3, device=dev, dtype=torch.float32)
+            dprev = torch.zeros(b, 3, h // 2, w // 2, device=dev, dtype=torch.float32) if rec["has_prev"] else None
+            accumulate = drows is not None
+            if drows is None:
+                drows = torch.empty_like(rows)
+            ops.rgb_head_bwd(drgb, w2d(stage.to_rgb).contiguous(), rows, drows, accumulate, dprev, dw_rgb, db_rgb, b, h, w, c)
+            grads[stage.to_rgb.weight] = dw_rgb.reshape(stage.to_rgb.weight.shape)
+            grads[stage.to_rgb.bias] = db_rgb
+            drgb = dprev
+            for blk_rec in reversed(rec["blocks"]):
+                blk, x, y1, t2 = blk_rec["blk"], blk_rec["x"], blk_rec["y1"], blk_rec["t2"]
+                d2 = ops.lrelu_bwd(drows, t2, SLOPE)                                  # at c2's pre-activation
+                _conv_grads(d2, y1, (b, h, w), blk.c2, grads)
+                dy1 = _conv(d2, (b, h, w), _pack3x3_dgrad(blk.c2.weight), None, c, c, ops.ACT_NONE)
+                d1 = ops.lrelu_bwd(dy1, y1, SLOPE)
+                _conv_grads(d1, x, (b, h, w), blk.c1, grads)
+                drows = _conv(d1, (b, h, w), _pack3x3_dgrad(blk.c1.weight), None, c, c, ops.ACT_NONE, addend=drows)     # + the skip path
+            if rec["up"] is not None:
+                up, x_in, packed, (hc, wc) = rec["up"]["conv"], rec["up"]["x"], rec["up"]["packed"], rec["up"]["hw"]
+                cin, cout = up.weight.shape[0], up.weight.shape[1]
+                d4 = ops.space_to_depth2(drows, b, hc, wc, cout)                       # [M_coarse, 4 Cout]
+                d4r = _Rows(d4)
+                dwp = grad_weight_rows(d4r, _Rows(x_in), d4.shape[0])                  # [(dy, dx, co)][ci]
+                grads[up.weight] = dwp.reshape(2, 2, cout, cin).permute(3, 2, 0, 1).contiguous()
+                grads[up.bias] = d4r.colsum().reshape(4, cout).sum(0)
+                drows = torch.empty(d4.shape[0], cin, device=dev, dtype=torch.float32)
+                ops.gemm(d4, d4.shape[0], cin, 4 * cout, [packed.t().contiguous()], drows)
+        # stem (vae.py:124): 1x1 conv from NCHW
+        b, cz, h0, w0 = z.shape
+        c0 = dec.input_layer.weight.shape[0]
+        dw0 = torch.empty(c0, cz, device=dev, dtype=torch.float32)
+        ops.stem_bwd(z, drows, dw0, b, cz, h0 * w0, c0)
+        grads[dec.input_layer.weight] = dw0.reshape(dec.input_layer.weight.shape)
+        grads[dec.input_layer.bias] = ops.colsum(drows, drows.shape[0], c0)
+        dz = None
+        if fctx.needs_input_grad[1]:
+            dz = torch.empty_like(z)
+            ops.head_nchw(drows, w2d(dec.input_layer).contiguous(), None, dz, b, c0, h0 * w0, cz)
+        return (None, dz) + tuple(grads.get(p) for p in fctx.params)

@@ -352,6 +352,32 @@ def encoder_cases():
     save("encoder_full", x=x, z=full(x))
 
 
+def decoder_bwd_cases():
+    """Decoder backward (vae.py:99-132) through the REFERENCE's autograd: a three-stage decoder with 64-channel first stage (the wide
+    weight-gradient route needs multiples of 128 -- the tiny net takes the narrow one; a 128-channel two-stage net takes the wide one),
+    loss = sum(y * g) with a fixed g: every parameter gradient and dL/dz."""
+    arrs = {}
+    for tag, kw, zshape in (("a", dict(channels=[64, 32, 32], stages=[1, 2, 1]), (2, 8, 8, 4)),
+                            ("b", dict(channels=[128, 128], stages=[1, 1]), (1, 8, 8, 8))):
+        dec = load_formula(ref_vae.Decoder(**kw))
+        z = g("decb.z" + tag, zshape).clone().requires_grad_()
+        y = dec(z)
+        gy = g("decb.g" + tag, tuple(y.shape))
+        (y * gy).sum().backward()
+        arrs["z_" + tag], arrs["g_" + tag], arrs["y_" + tag], arrs["dz_" + tag] = z.detach(), gy, y.detach(), z.grad
+        names = []
+        for k, p_ in dec.named_parameters():
+            if p_.grad is not None:
+                names.append(k)
+                if tag == "a":
+                    arrs["grad_%s_%s" % (tag, k)] = p_.grad
+                else:                                    # wide net: norm + a corner of every gradient (keeps the fixture small)
+                    arrs["gradnorm_%s_%s" % (tag, k)] = p_.grad.double().norm()
+                    arrs["gradslice_%s_%s" % (tag, k)] = p_.grad.reshape(p_.grad.shape[0], -1)[:32, :96].clone()
+        arrs["names_" + tag] = np.array(names)
+    save("decoder_bwd", **arrs)
+
+
 def vq_cases():
     """VectorQuantizer (vae.py:7-26) on its default codebook size (8192 x 8): indices, embedding rows, the two-sided L1 loss and its
     gradients, plus VAE.calclate_loss's forward on a tiny encoder / decoder with the noise replayed.  The codebook gets three
@@ -401,6 +427,9 @@ if __name__ == "__main__":
     if "--encoder-only" in sys.argv:
         encoder_cases()
         sys.exit(0)
+    if "--decoder-bwd-only" in sys.argv:
+        decoder_bwd_cases()
+        sys.exit(0)
     tables()
     schedule()
     module_cases()
@@ -410,4 +439,5 @@ if __name__ == "__main__":
     loss_full_cases()
     vae_cases()
     encoder_cases()
+    decoder_bwd_cases()
     vq_cases()
