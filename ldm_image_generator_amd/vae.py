@@ -9,8 +9,8 @@ bilinear RGB accumulation are one fused HBM-bound kernel per stage.
 
 ``Encoder`` (latent pre-encoding for train_ldm.py) reuses the same kernels.  SURVEY 8f.4 (VAE training) is started
 with its integer part: ``VectorQuantizer`` (quantize with the reference's indices, embed, the two-sided L1 loss with gradients) and
-the forward of ``VAE.calclate_loss``; ``Decoder`` is differentiable (``vae_train.DecoderFunction``: parameter gradients and dL/dz,
-pinned against the reference's autograd); the ``Discriminator`` and the Encoder backward are not provided.
+``VAE.calclate_loss``; ``Encoder`` and ``Decoder`` are differentiable (``vae_train.py``: parameter gradients and input gradients,
+pinned against the reference's autograd), so the VAE objective trains end to end; the ``Discriminator`` is not provided.
 """
 import torch
 import torch.nn as nn
@@ -108,6 +108,9 @@ class Encoder(nn.Module):
         self._out_t = _PackedWeight(lambda w: w.reshape(w.shape[0], -1).t())          # [C, latent] for the head kernel
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .vae_train import EncoderFunction                     # training: same kernels + tape, hand-written backward
+            return EncoderFunction.apply(self, x, *[p for p in self.parameters() if p.requires_grad])
         b, cin, h, w = x.shape
         dev = x.device
         c0 = self.input_layer.weight.shape[0]
@@ -235,8 +238,7 @@ class VectorQuantizer(nn.Module):
 
 class VAE(nn.Module):
     """vae.py:30-52.  ``encode`` / ``decode`` are the sampling path; ``calclate_loss`` (sic) is the FORWARD of the VAE training
-    objective (the Decoder has its backward, ``vae_train.py``; the Encoder's -- avg-pool + 1x1 + the same dense 3x3 pieces -- is not
-    wired yet, so the call as a whole is only valid under ``torch.no_grad()``)."""
+    objective, differentiable end to end (``vae_train.py``)."""
 
     def __init__(self, encoder, decoder, quantizer):
         super().__init__()
@@ -245,10 +247,17 @@ class VAE(nn.Module):
         self.quantizer = quantizer
 
     def calclate_loss(self, x, noise_gain=0.1):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("VAE.calclate_loss: only the forward is implemented on the HIP path; call it under torch.no_grad()")
+        """-> (loss_recon, loss_reg, y) as vae.py:36-43; differentiable: Encoder, Decoder and the quantizer's embeddings get their
+        gradients through hand-written backward kernels (vae_train.py, train.L1LossFunction, _VQLossFunction)."""
         z = self.encoder(x)
         noise = torch.randn(z.shape, device=x.device)
+        if torch.is_grad_enabled() and z.requires_grad:
+            from .train import L1LossFunction
+            from .vae_train import AddNoiseFunction, ToRowsFunction
+            z = AddNoiseFunction.apply(z, noise, float(noise_gain))
+            loss_reg = self.quantizer.calculate_loss(ToRowsFunction.apply(z))
+            y = self.decoder(z)
+            return L1LossFunction.apply(y, x.detach()), loss_reg, y
         b = z.shape[0]
         zn = torch.empty_like(z)                          # z * 1 + noise * gain, products and sum rounded like torch's two ops
         ops.qsample(z, noise, torch.ones(b, device=x.device), torch.full((b,), float(noise_gain), device=x.device), zn)

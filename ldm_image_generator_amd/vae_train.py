@@ -46,6 +46,26 @@ def _conv_grads(dy, x, shape, conv, grads):
     grads[conv.bias] = dyr.colsum().clone()
 
 
+def _resblock_forward(blk, rows, shape, tape):
+    """x + lrelu(c2(lrelu(c1(x))))  (vae.py:60-66) keeping x, the activated hidden and the activated branch."""
+    c = rows.shape[1]
+    y1 = _conv(rows, shape, _pack3x3(blk.c1.weight), blk.c1.bias.detach(), c, c, ops.ACT_LRELU)
+    t2 = _conv(y1, shape, _pack3x3(blk.c2.weight), blk.c2.bias.detach(), c, c, ops.ACT_LRELU)
+    tape.append(dict(blk=blk, x=rows, y1=y1, t2=t2))
+    return ops.add_(t2.clone(), rows)
+
+
+def _resblock_backward(rec, drows, shape, grads):
+    blk, x, y1, t2 = rec["blk"], rec["x"], rec["y1"], rec["t2"]
+    c = x.shape[1]
+    d2 = ops.lrelu_bwd(drows, t2, SLOPE)                                  # at c2's pre-activation
+    _conv_grads(d2, y1, shape, blk.c2, grads)
+    dy1 = _conv(d2, shape, _pack3x3_dgrad(blk.c2.weight), None, c, c, ops.ACT_NONE)
+    d1 = ops.lrelu_bwd(dy1, y1, SLOPE)
+    _conv_grads(d1, x, shape, blk.c1, grads)
+    return _conv(d1, shape, _pack3x3_dgrad(blk.c1.weight), None, c, c, ops.ACT_NONE, addend=drows)          # + the skip path
+
+
 class DecoderFunction(torch.autograd.Function):
     """vae.py:122-132 forward + backward.  ``params`` only anchors the graph."""
 
@@ -70,14 +90,10 @@ class DecoderFunction(torch.autograd.Function):
                 rec["up"] = dict(conv=up, x=rows, packed=packed, hw=(h, w))
                 rows, h, w = fine, 2 * h, 2 * w
             shape = (b, h, w)
-            c = rows.shape[1]
             for blk in stage.layers:
-                y1 = _conv(rows, shape, _pack3x3(blk.c1.weight), blk.c1.bias.detach(), c, c, ops.ACT_LRELU)
-                t2 = _conv(y1, shape, _pack3x3(blk.c2.weight), blk.c2.bias.detach(), c, c, ops.ACT_LRELU)
-                rec["blocks"].append(dict(blk=blk, x=rows, y1=y1, t2=t2))
-                rows = ops.add_(t2.clone(), rows)                                   # x + lrelu(c2(lrelu(c1(x))))  (vae.py:60-66)
+                rows = _resblock_forward(blk, rows, shape, rec["blocks"])
             new_rgb = torch.empty(b, 3, h, w, device=dev, dtype=torch.float32)
-            ops.rgb_head(rows, w2d(stage.to_rgb), stage.to_rgb.bias.detach(), rgb, new_rgb, b, h, w, c)
+            ops.rgb_head(rows, w2d(stage.to_rgb), stage.to_rgb.bias.detach(), rgb, new_rgb, b, h, w, rows.shape[1])
             rec.update(stage=stage, rows=rows, shape=shape, has_prev=rgb is not None)
             tape.append(rec)
             rgb = new_rgb
@@ -105,13 +121,7 @@ class DecoderFunction(torch.autograd.Function):
             grads[stage.to_rgb.bias] = db_rgb
             drgb = dprev
             for blk_rec in reversed(rec["blocks"]):
-                blk, x, y1, t2 = blk_rec["blk"], blk_rec["x"], blk_rec["y1"], blk_rec["t2"]
-                d2 = ops.lrelu_bwd(drows, t2, SLOPE)                                  # at c2's pre-activation
-                _conv_grads(d2, y1, (b, h, w), blk.c2, grads)
-                dy1 = _conv(d2, (b, h, w), _pack3x3_dgrad(blk.c2.weight), None, c, c, ops.ACT_NONE)
-                d1 = ops.lrelu_bwd(dy1, y1, SLOPE)
-                _conv_grads(d1, x, (b, h, w), blk.c1, grads)
-                drows = _conv(d1, (b, h, w), _pack3x3_dgrad(blk.c1.weight), None, c, c, ops.ACT_NONE, addend=drows)     # + the skip path
+                drows = _resblock_backward(blk_rec, drows, (b, h, w), grads)
             if rec["up"] is not None:
                 up, x_in, packed, (hc, wc) = rec["up"]["conv"], rec["up"]["x"], rec["up"]["packed"], rec["up"]["hw"]
                 cin, cout = up.weight.shape[0], up.weight.shape[1]
@@ -134,3 +144,111 @@ class DecoderFunction(torch.autograd.Function):
             dz = torch.empty_like(z)
             ops.head_nchw(drows, w2d(dec.input_layer).contiguous(), None, dz, b, c0, h0 * w0, cz)
         return (None, dz) + tuple(grads.get(p) for p in fctx.params)
+
+
+class EncoderFunction(torch.autograd.Function):
+    """vae.py:76-96 forward + backward: stem 1x1 from NCHW, ResBlocks, (avg-pool 2 -> 1x1 conv) between stages, 1x1 head to NCHW."""
+
+    @staticmethod
+    def forward(fctx, enc, x, *params):
+        from torch import nn
+        b, cin, h, w = x.shape
+        dev = x.device
+        x = x.contiguous().float()
+        c0 = enc.input_layer.weight.shape[0]
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x, w2d(enc.input_layer), enc.input_layer.bias.detach(), rows, b, cin, h * w, c0)
+        tape = []
+        for stage, down in zip(enc.stages, enc.downsamples):
+            rec = dict(blocks=[], shape=(b, h, w), down=None)
+            for blk in stage.seq:
+                rows = _resblock_forward(blk, rows, (b, h, w), rec["blocks"])
+            if not isinstance(down, nn.Identity):
+                conv = down[1]
+                c = rows.shape[1]
+                pooled = torch.empty(b * (h // 2) * (w // 2), c, device=dev, dtype=torch.float32)
+                ops.avgpool2(rows, pooled, b, h, w, c)
+                h, w = h // 2, w // 2
+                rows = torch.empty(b * h * w, conv.weight.shape[0], device=dev, dtype=torch.float32)
+                ops.gemm(pooled, b * h * w, conv.weight.shape[0], c, [w2d(conv)], rows, biases=[conv.bias.detach()])
+                rec["down"] = dict(conv=conv, pooled=pooled)
+            tape.append(rec)
+        cz = enc.output_layer.weight.shape[0]
+        z = torch.empty(b, cz, h, w, device=dev, dtype=torch.float32)
+        w_t = enc.output_layer.weight.detach().reshape(cz, -1).t().contiguous()                 # [C, latent]
+        ops.head_nchw(rows, w_t, enc.output_layer.bias.detach(), z, b, rows.shape[1], h * w, cz)
+        fctx.enc, fctx.tape, fctx.x, fctx.params, fctx.last, fctx.w_t, fctx.hw = enc, tape, x, params, rows, w_t, (h, w)
+        return z
+
+    @staticmethod
+    def backward(fctx, dz):
+        enc, tape, x, rows, w_t, (h, w) = fctx.enc, fctx.tape, fctx.x, fctx.last, fctx.w_t, fctx.hw
+        dev = dz.device
+        b, cin = x.shape[0], x.shape[1]
+        grads = {}
+        c, cz = rows.shape[1], enc.output_layer.weight.shape[0]
+        drows = torch.empty_like(rows)
+        dwl = torch.empty(c, cz, device=dev, dtype=torch.float32)
+        dbl = torch.empty(cz, device=dev, dtype=torch.float32)
+        ops.head_bwd(rows, w_t, dz.contiguous().float(), drows, dwl, dbl, b, c, h * w, cz)
+        grads[enc.output_layer.weight] = dwl.t().reshape(enc.output_layer.weight.shape).contiguous()
+        grads[enc.output_layer.bias] = dbl
+        for rec in reversed(tape):
+            bb, hh, ww = rec["shape"]
+            if rec["down"] is not None:                                   # rows_coarse = conv1x1(avgpool2(rows_fine))
+                conv, pooled = rec["down"]["conv"], rec["down"]["pooled"]
+                cout, cfine = conv.weight.shape[0], conv.weight.shape[1]
+                dr = _Rows(drows)
+                grads[conv.weight] = grad_weight_rows(dr, _Rows(pooled), drows.shape[0]).reshape(conv.weight.shape)
+                grads[conv.bias] = dr.colsum().clone()
+                dpooled = torch.empty_like(pooled)
+                ops.gemm(drows, drows.shape[0], cfine, cout, [w2d(conv).t().contiguous()], dpooled)
+                drows = torch.empty(bb * hh * ww, cfine, device=dev, dtype=torch.float32)
+                ops.avgpool2_bwd(dpooled, drows, bb, hh, ww, cfine, False)
+            for blk_rec in reversed(rec["blocks"]):
+                drows = _resblock_backward(blk_rec, drows, (bb, hh, ww), grads)
+        c0 = enc.input_layer.weight.shape[0]
+        h0, w0 = x.shape[2], x.shape[3]
+        dw0 = torch.empty(c0, cin, device=dev, dtype=torch.float32)
+        ops.stem_bwd(x, drows, dw0, b, cin, h0 * w0, c0)
+        grads[enc.input_layer.weight] = dw0.reshape(enc.input_layer.weight.shape)
+        grads[enc.input_layer.bias] = ops.colsum(drows, drows.shape[0], c0)
+        dx = None
+        if fctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            ops.head_nchw(drows, w2d(enc.input_layer).contiguous(), None, dx, b, c0, h0 * w0, cin)
+        return (None, dx) + tuple(grads.get(p) for p in fctx.params)
+
+
+class AddNoiseFunction(torch.autograd.Function):
+    """z + noise * gain (vae.py:38) with torch's two roundings; dL/dz passes through."""
+
+    @staticmethod
+    def forward(fctx, z, noise, gain):
+        b = z.shape[0]
+        out = torch.empty_like(z)
+        ops.qsample(z.contiguous(), noise, torch.ones(b, device=z.device), torch.full((b,), float(gain), device=z.device), out)
+        return out
+
+    @staticmethod
+    def backward(fctx, g):
+        return g, None, None
+
+
+class ToRowsFunction(torch.autograd.Function):
+    """z [B, C, h, w] -> [B*h*w, C] (== z.reshape(B, C, -1).transpose(1, 2), vae.py:40) and back for the gradient."""
+
+    @staticmethod
+    def forward(fctx, z):
+        b, c, h, w = z.shape
+        fctx.shape = (b, c, h, w)
+        rows = torch.empty(b * h * w, c, device=z.device, dtype=torch.float32)
+        ops.nchw_to_nhwc(z.contiguous().float(), rows, b, c, h * w)
+        return rows
+
+    @staticmethod
+    def backward(fctx, g):
+        b, c, h, w = fctx.shape
+        out = torch.empty(b, c, h, w, device=g.device, dtype=torch.float32)
+        ops.nhwc_to_nchw(g.contiguous().float(), out, b, c, h * w)
+        return out

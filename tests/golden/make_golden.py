@@ -378,6 +378,35 @@ def decoder_bwd_cases():
     save("decoder_bwd", **arrs)
 
 
+def vae_bwd_cases():
+    """VAE.calclate_loss (vae.py:36-43) WITH gradients through the reference's autograd: (loss_recon + loss_reg).backward() on a tiny
+    encoder / decoder / 512-entry codebook, latent noise replayed; norm + a corner of every parameter gradient."""
+    enc = load_formula(ref_vae.Encoder(channels=[32, 64, 32], stages=[1, 2, 1]))
+    dec = load_formula(ref_vae.Decoder(channels=[64, 32, 32], stages=[1, 2, 1]))
+    vq2 = ref_vae.VectorQuantizer(num_embeddings=512, dim=8)
+    with torch.no_grad():
+        vq2.embeddings.copy_(g("vq2.emb", (512, 8)) * 0.2)
+    vae = ref_vae.VAE(enc, dec, vq2)
+    img = g("vaeb.x", (2, 3, 32, 32))
+    torch.manual_seed(12)
+    st = torch.get_rng_state()
+    with torch.no_grad():
+        z0 = enc(img)
+    noise = torch.randn(z0.shape)
+    torch.set_rng_state(st)
+    loss_recon, loss_reg, y = vae.calclate_loss(img, noise_gain=0.1)
+    (loss_recon + loss_reg).backward()
+    arrs = dict(x=img, noise=noise, emb=vq2.embeddings.detach().clone(), loss_recon=loss_recon.detach(), loss_reg=loss_reg.detach(), y=y.detach())
+    names = []
+    for k, p_ in vae.named_parameters():
+        if p_.grad is not None:
+            names.append(k)
+            arrs["gradnorm_" + k] = p_.grad.double().norm()
+            arrs["gradslice_" + k] = p_.grad.reshape(p_.grad.shape[0], -1)[:32, :96].clone()
+    arrs["names"] = np.array(names)
+    save("vae_bwd", **arrs)
+
+
 def vq_cases():
     """VectorQuantizer (vae.py:7-26) on its default codebook size (8192 x 8): indices, embedding rows, the two-sided L1 loss and its
     gradients, plus VAE.calclate_loss's forward on a tiny encoder / decoder with the noise replayed.  The codebook gets three
@@ -429,6 +458,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--decoder-bwd-only" in sys.argv:
         decoder_bwd_cases()
+        vae_bwd_cases()
         sys.exit(0)
     tables()
     schedule()
@@ -440,4 +470,5 @@ if __name__ == "__main__":
     vae_cases()
     encoder_cases()
     decoder_bwd_cases()
+    vae_bwd_cases()
     vq_cases()
