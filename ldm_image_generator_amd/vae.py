@@ -237,7 +237,7 @@ class VectorQuantizer(nn.Module):
 
 
 class VAE(nn.Module):
-    """vae.py:30-52.  ``encode`` / ``decode`` are the sampling path; ``calclate_loss`` (sic) is the FORWARD of the VAE training
+    """vae.py:30-52.  ``encode`` / ``decode`` are the sampling path; ``calclate_loss`` (sic) is the VAE training
     objective, differentiable end to end (``vae_train.py``)."""
 
     def __init__(self, encoder, decoder, quantizer):
