@@ -119,6 +119,7 @@ def main():
     lo, hi = ldist.shard_bounds(gb, rank, world)
     x_t = ldist.global_noise(gb, (8, 32, 32), seed=0)[lo:hi].to(dev)
 
+    @torch.no_grad()                   # VAE.decode (vae.py:50-52) is a no_grad method; with gradients enabled Decoder.forward keeps a training tape
     def decode(z):
         img = dec(z)
         return to_uint8_images(img) if args.gather == "u8" else img

@@ -14,6 +14,7 @@ for B in [int(v) for v in sys.argv[1:]] or (1, 4, 16):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         z = d.sample((B, 8, 32, 32), seed=it, num_steps=50, progress=False)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        img = dec(z)
+        with torch.no_grad():
+            img = dec(z)
         torch.cuda.synchronize(); t2 = time.perf_counter()
     print("B=%d: sample %.1f ms (%.2f ms/step), decode %.1f ms, %.2f images/s" % (B, (t1 - t0) * 1e3, (t1 - t0) * 20, (t2 - t1) * 1e3, B / (t2 - t0)), flush=True)
