@@ -157,7 +157,7 @@ def main():
         return max_over_ranks(dt), prof + (abytes,), out
 
     # what produced `value`: the process-wide GEMM knobs as the library reports them (LDM_GEMM_VARIANT in the environment would show here)
-    knobs = {"gemm_variant": ops.gemm_variant(-1), "wide_epilogue": ops.gemm_wide_epilogue(-1)}
+    knobs = {"gemm_variant": ops.gemm_variant(-1), "wide_epilogue": ops.gemm_wide_epilogue(-1), "gemm_ring": ops.gemm_ring(-1)}
     dt, (launches, gemm_ms, gemm_flops, gemm_bytes), out = measure(args.warmup, args.steps)
     finite = bool(torch.isfinite(out.float()).all().item())
 
@@ -296,7 +296,7 @@ def main():
             "denoise_steps_per_sec": images * T / dt / B, "sample_steps_per_sec": images * T / dt,
             "algorithmic_tflops": algo_flops / dt / 1e12 if args.mode == "eval" else None,
             "outputs_finite": finite,
-            "gemm_variant": knobs["gemm_variant"], "wide_epilogue": knobs["wide_epilogue"],
+            "gemm_variant": knobs["gemm_variant"], "wide_epilogue": knobs["wide_epilogue"], "gemm_ring": knobs["gemm_ring"],
             "gemm_variant_note": "1 = exact fp32 (v_mfma_f32_32x32x2_f32), the schedule `value` was measured under; 2 appears only in split_schedule",
             "roofline": {"bound": "mfma", "kernel": "ldm_gemm_f32 family (gemm_stream_kernel, gconv3x3_kernel; v_mfma_f32_32x32x2_f32), all launches of the timed region",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
