@@ -298,7 +298,7 @@ def main():
             "outputs_finite": finite,
             "gemm_variant": knobs["gemm_variant"], "wide_epilogue": knobs["wide_epilogue"], "gemm_ring": knobs["gemm_ring"],
             "gemm_variant_note": "1 = exact fp32 (v_mfma_f32_32x32x2_f32), the schedule `value` was measured under; 2 appears only in split_schedule",
-            "roofline": {"bound": "mfma", "kernel": "ldm_gemm_f32 family (gemm_stream_kernel, gconv3x3_kernel; v_mfma_f32_32x32x2_f32), all launches of the timed region",
+            "roofline": {"bound": "mfma", "kernel": "ldm_gemm_f32 family (gemm_ring_kernel, gemm_stream_kernel, gconv3x3_pipe_kernel; v_mfma_f32_32x32x2_f32), all launches of the timed region",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": launches, "kernel_ms": gemm_ms,

@@ -17,7 +17,7 @@ SIMDS = 256 * 4
 
 def short_name(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    for k in ("gemm_stream_kernel", "gemm_f32_kernel"):
+    for k in ("gemm_stream_kernel", "gemm_ring_kernel", "gemm_f32_kernel"):
         if k in name:
             return name[name.find(k):].split("(")[0]
     return name.split("(")[0].split("<")[0][-48:]

@@ -12,7 +12,7 @@ import sys
 
 def short_name(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    for k in ("gemm_stream_kernel", "gemm_f32_kernel"):
+    for k in ("gemm_stream_kernel", "gemm_ring_kernel", "gemm_f32_kernel"):
         if k in name:
             return name[name.find(k):].split("(")[0]
     return name.split("(")[0].split("<")[0][-48:]
@@ -53,7 +53,7 @@ if __name__ == "__main__":
             tot[1] += 2 * fb + wb
             tot[2] += ns
     summary = dict(gemm_launches=tot[0], gemm_hbm_bytes_per_launch=tot[1] / max(tot[0], 1),
-                   gemm_avg_us=tot[2] / max(tot[0], 1) / 1e3, kernels=rows[:12])
+                   gemm_avg_us=tot[2] / max(tot[0], 1) / 1e3, kernels=rows[:14])
     # ALGORITHMIC bytes per launch of the two dominant instances at the bench workload (B = 256, latent 32x32: M = 262144 >> level,
     # C = 128 << level, 6 / 6 / 18 / 6 SwinBlocks per level), every operand once:
     #   gated MoE GEMM: reads x [M, C] + 2 x 3 weight matrices [C, C], writes the hidden [M, 3C]
@@ -62,12 +62,16 @@ if __name__ == "__main__":
     gate_r = sum(n * ((262144 >> (2 * i)) * (128 << i) * 4 + 6 * (128 << i) ** 2 * 4) for i, n in enumerate(blocks)) / 36.0
     gate_w = sum(n * ((262144 >> (2 * i)) * 3 * (128 << i) * 4) for i, n in enumerate(blocks)) / 36.0
     inst = {}
-    for r in rows:
-        if r["kernel"].startswith("gemm_stream_kernel<2, 2, 2, 1, true, 0, 0, true"):
-            inst["gated MoE GEMM"] = dict(kernel=r["kernel"], algorithmic_fetch=gate_r, algorithmic_write=gate_w,
-                                          fetch_over_algorithmic=r["fetch_bytes_x2_per_launch"] / gate_r,
-                                          write_over_algorithmic=r["write_bytes_per_launch"] / gate_w,
-                                          total_over_algorithmic=(r["fetch_bytes_x2_per_launch"] + r["write_bytes_per_launch"]) / (gate_r + gate_w))
+    # the gated GEMM runs on two kernels since round 2: the ring kernel's gated instance (stages 0-2) and the stream kernel's (stage 3)
+    gate_rows = [r for r in rows if r["kernel"].startswith("gemm_stream_kernel<2, 2, 2, 1, true, 0, 0, true") or
+                 r["kernel"].startswith("gemm_ring_kernel<0, 2, true")]
+    if gate_rows:
+        n = sum(r["launches"] for r in gate_rows)
+        fb = sum(r["fetch_bytes_x2_per_launch"] * r["launches"] for r in gate_rows) / n
+        wb = sum(r["write_bytes_per_launch"] * r["launches"] for r in gate_rows) / n
+        inst["gated MoE GEMM"] = dict(kernel=" + ".join(r["kernel"] for r in gate_rows), launches=n, algorithmic_fetch=gate_r, algorithmic_write=gate_w,
+                                      fetch_over_algorithmic=fb / gate_r, write_over_algorithmic=wb / gate_w,
+                                      total_over_algorithmic=(fb + wb) / (gate_r + gate_w))
     summary["per_instance"] = inst
     json.dump(summary, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
     with open("profiles/%s_traffic.md" % tag, "w") as out:
@@ -76,7 +80,7 @@ if __name__ == "__main__":
         out.write("FETCH_SIZE x2 (gfx950 wide-stream correction), WRITE_SIZE as read.  GEMM family: %d launches, "
                   "%.1f MB per launch on average, %.1f us per launch (profiled).\n\n" % (tot[0], summary["gemm_hbm_bytes_per_launch"] / 1e6, summary["gemm_avg_us"]))
         out.write("| kernel | launches | fetch x2 MB/launch | write MB/launch | avg us |\n|---|---|---|---|---|\n")
-        for r in rows[:12]:
+        for r in rows[:14]:
             out.write("| `%s` | %d | %.1f | %.1f | %.1f |\n" % (r["kernel"][:70], r["launches"], r["fetch_bytes_x2_per_launch"] / 1e6,
                                                            r["write_bytes_per_launch"] / 1e6, r["avg_us"]))
     print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
