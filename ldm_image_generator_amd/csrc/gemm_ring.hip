@@ -483,7 +483,7 @@ int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32)
     if (!any && fp32 && p.addend && p.K < 384) return 0;
     if (gate) return (unit % 128 == 0 && fills(mt * (p.N / 128))) ? 2 : 0;
     if (unit % 256 == 0 && fills(mt * (p.N / 256))) return 2;
-    if (fp32 && unit % 128 == 0 && (any || !p.addend) && fills(mt * (p.N / 128))) return 1;
+    if (fp32 && unit % 128 == 0 && (any || !p.addend || p.K >= 384) && fills(mt * (p.N / 128))) return 1;
     return 0;
 }
 
