@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=128, help="training-step leg: samples per GPU (cfg 5: 1024 / 8)")
     ap.add_argument("--train-latent", type=int, default=64, help="training-step leg: latent edge (512 px / 8)")
     ap.add_argument("--train-steps", type=int, default=3, help="training-step leg: timed optimisation steps")
+    ap.add_argument("--train-warmup", type=int, default=2, help="training-step leg: untimed steps before the timed ones")
     args = ap.parse_args()
 
     from ldm_image_generator_amd import dist as ldist
@@ -229,11 +230,12 @@ def main():
                          generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
         train_step = {"unit": "samples/s", "config": {"workload": "train_ldm step, latents [%d, 8, %d, %d] per GPU, UNet(385.7M) train mode, "
                                                                   "L1 loss, torch.optim.AdamW(fused=True)" % (args.train_batch, args.train_latent, args.train_latent),
-                                                      "global_batch": args.train_batch * world, "steps": args.train_steps, "warmup": 1}}
+                                                      "global_batch": args.train_batch * world, "steps": args.train_steps, "warmup": args.train_warmup}}
         for prec in getattr(ltrain, "PRECISIONS", ("f32",)):
             ltrain.set_precision(net, prec) if hasattr(ltrain, "set_precision") else None
             torch.cuda.reset_peak_memory_stats()
-            ldist.train_step(ddpm, opt, xb, 0, world)                              # warm-up: allocator, RCCL buffers, weight caches
+            for wi in range(args.train_warmup):                                   # warm-up: allocator, RCCL buffers, weight caches, and the
+                ldist.train_step(ddpm, opt, xb, 10000 + wi, world)                # optimizer state of the experts a step happens to pick
             fence()
             ops.prof_enable(rank == 0)
             t0 = time.perf_counter()
