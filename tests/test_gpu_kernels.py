@@ -508,3 +508,38 @@ def test_gemm_ring_kernel_fp32_bit_identical_to_stream_kernel(ops, gpu_device, M
         ops.gemm_ring(old)
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
     assert rel_l2(outs[2].double().cpu(), ref.cpu()) < KTOL
+
+
+def test_gemm_split_schedule_on_nonfinite_and_denormal_operands(ops, gpu_device):
+    """Schedule 2 (three exact bf16 pieces per fp32 value) against schedule 1 (exact fp32) on operands a checkpoint can contain:
+    inf / NaN (non-finite results land in the SAME output elements; the split turns an inf operand into NaN because inf - inf appears
+    in its residual), denormal operands (their low pieces are flushed: up to ~10 % RELATIVE error on results that are themselves
+    ~1e-40 ... 1e-28, i.e. an absolute difference below 2e-29 here), values whose products overflow."""
+    M, N, K = 256, 128, 128
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    a[3, 5] = float("inf")
+    a[7, 0] = float("nan")
+    a[9, :] = 1e-40                                   # denormal row
+    a[11, :] = 1e30
+    w[4, :] = 1e10                                    # row 11 x column 4 overflows
+    a[13, 17] = -float("inf")
+    outs = {}
+    old = ops.gemm_variant(1)
+    try:
+        for v in (1, 2):
+            ops.gemm_variant(v)
+            out = torch.empty(M, N, device=gpu_device)
+            ops.gemm(a.cuda(), M, N, K, [w.cuda()], out)
+            outs[v] = out.cpu()
+    finally:
+        ops.gemm_variant(old)
+    f1, f2 = torch.isfinite(outs[1]), torch.isfinite(outs[2])
+    assert torch.equal(f1, f2)                                             # same non-finite pattern ...
+    assert not f1[3].any() and not f1[7].any() and not f1[13].any() and not bool(f1[11, 4])
+    assert bool(f1[0].all()) and bool(f1[9].all())
+    fin = f1.clone()
+    fin[9] = False
+    assert rel_l2(outs[2][fin], outs[1][fin]) < 2e-6                      # ... fp32-level agreement elsewhere
+    assert float((outs[2][9] - outs[1][9]).abs().max()) < 2e-29           # denormal row (against weights up to 1e10)
