@@ -24,11 +24,17 @@ def rel(a, b):
 
 
 def run_all(fn):
+    """schedules 0 (tile), 1 (stream; ring kernel off), 2 (split consumer), then 1 with the ring kernel forced on at most eight
+    workgroups (many tiles per workgroup) for every shape it takes"""
     outs = []
+    ring = o.gemm_ring(0)
     for v in (0, 1, 2):
         old = o.gemm_variant(v)
         outs.append(fn())
         o.gemm_variant(old)
+    o.gemm_ring(3)
+    outs.append(fn())
+    o.gemm_ring(ring)
     return outs
 
 
@@ -36,7 +42,7 @@ bad = 0
 for ci in range(cases):
     kind = rng.choice(["plain", "plain", "gate", "kseg", "conv", "gconv"])
     if kind in ("plain", "gate", "kseg"):
-        M = rng.choice([1, 7, 32, 100, 129, 300, 1000, 2500, 4100, 9000])
+        M = rng.choice([1, 7, 32, 100, 129, 300, 1000, 2500, 4100, 9000, 256, 512, 1024, 2048, 4096, 6144])
         C = rng.choice([32, 64, 96, 128, 256, 384])
         nseg = rng.choice([1, 2, 3])
         act = rng.choice([o.ACT_NONE, o.ACT_RELU, o.ACT_LRELU])
@@ -110,9 +116,9 @@ for ci in range(cases):
                 return out
     outs = run_all(fn)
     e = [rel(t, ref) for t in outs]
-    ok = torch.equal(outs[0], outs[1]) and max(e) < 1e-5
+    ok = torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3]) and max(e) < 1e-5
     if not ok:
         bad += 1
-        print("MISMATCH case %d %s: errors %s, tile==stream %s" % (ci, kind, e, torch.equal(outs[0], outs[1])), flush=True)
+        print("MISMATCH case %d %s: errors %s, tile==stream %s, tile==ring %s" % (ci, kind, e, torch.equal(outs[0], outs[1]), torch.equal(outs[0], outs[3])), flush=True)
 print("%d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
