@@ -11,6 +11,7 @@ using namespace ldmgemm;
 
 int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate);
 int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st);      // gemm_ring.hip: 256-row tiles, one workgroup per CU, four-stage ring
+int ldm_gemm_ring_dispatch_bf16_gate(const GemmP &p, int groups, hipStream_t st);
 
 namespace {
 
@@ -69,7 +70,7 @@ int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mo
     void *rec = ldm_prof_begin(LDM_PROF_GEMM_BF16, 2.0 * mn * d->K * (mode == 1 ? 2.0 : 1.0), st,
                                2.0 * ((double)d->M * d->K * (d->a_gstride || groups == 1 ? groups : 1) + (double)d->N * d->K * groups * (mode == 1 ? 2.0 : 1.0)) +
                                    mn * (out_bf16 ? 2.0 : 4.0) * out_planes + (mode == 2 ? mn * 4.0 : 0.0) + (d->addend ? mn * 4.0 : 0.0));
-    const int ok = (mode == 0 && ldm_gemm_ring_dispatch_bf16(p, groups, out_bf16 != 0, st)) || ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st, mode == 1);
+    const int ok = (mode == 0 && ldm_gemm_ring_dispatch_bf16(p, groups, out_bf16 != 0, st)) || (mode == 1 && ldm_gemm_ring_dispatch_bf16_gate(p, groups, st)) || ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st, mode == 1);
     ldm_prof_end(rec, st);
     LDM_REQUIRE(ok, "%s: no kernel instance for this shape (N=%d, seg_len=%d)", who, d->N, seg_len);
     LDM_CHECK_LAUNCH(who);

@@ -71,7 +71,7 @@ __device__ __forceinline__ float ring_gload(const float *ptr)
 
 // ET: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 bf16 (v_mfma_f32_32x32x16_bf16); NJ: accumulator columns per wave (tile = 256 x 128 NJ);
 // GATE (NJ == 2): tile = 256 x 128 hidden columns; OBF: bf16 output (ET == 1, NJ == 2, plain)
-template <int ET, int NJ, bool GATE, bool OBF, bool ADD>
+template <int ET, int NJ, bool GATE, bool OBF, bool ADD, bool GF = false>
 __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     static_assert(!GATE || NJ == 2, "gate: two accumulator columns (a, b)");
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     constexpr int BN = GATE ? 128 : 128 * NJ;                      // output columns per tile
     constexpr int RPW = 2 + NJ;                                    // LDS-DMA instructions per wave and step (2 x A, NJ x W)
     constexpr int NM = (ET ? 1 : 4) * 4 * NJ;                      // MFMAs of one slice
-    constexpr int NSTORE = (OBF || GATE) ? 16 : 16 * NJ;           // 16-byte row stores per wave and tile in the epilogue
+    static_assert(!GF || (ET == 1 && GATE && !OBF && !ADD), "bf16 gate forward with saved pre-activations: the gated bf16 instance");
+    constexpr int NSTORE = GF ? 48 : (OBF || GATE) ? 16 : 16 * NJ;  // row stores per wave and tile in the epilogue
     constexpr int NBIAS = GATE ? 2 : 4 * NJ;                       // bias loads per lane and tile (issued at the tile's start)
     extern __shared__ __attribute__((aligned(16))) char rlds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -344,7 +345,31 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                 else if constexpr (ACT == LDM_ACT_LRELU) v = v > 0.f ? v : v * slope;
                 return v;
             };
-            if constexpr (OBF) {
+            if constexpr (GF) {
+                // ReGLU forward of the bf16 training step: hid = (a + ba) relu(b + bb) AND the two pre-activations, all bf16 [M, ldo];
+                // three passes of each 32 x 32 fp32 piece through the scratch, 4 columns (8 bytes) per lane
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const int ldo_ = (int)p.ldo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pass = 0; pass < 3; ++pass) {
+                        unsigned short *o16 = (unsigned short *)(pass == 0 ? p.out : (pass == 1 ? p.out2 : p.out3));
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float av = acc[i][0][e] + b1[0], gt = acc[i][1][e] + b2;
+                            const float v = pass == 0 ? av * fmaxf(gt, 0.f) : (pass == 1 ? av : gt);
+                            const int slot = h | (e & 2) | ((e & 1) << 2) | ((e >> 2) << 3);
+                            *(float *)(scr + slot * 128 + r * 4) = v;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 v = *(const f32x4 *)(scr + (8 * k + rsub) * 128 + cc * 16);
+                            *(u32x2 *)(o16 + (orow0 + i * 32 + 8 * k + rrow) * ldo_ + c_n0 + wn * 32 + cc * 4) =
+                                u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        }
+                    }
+            } else if constexpr (OBF) {
                 unsigned short *o16 = (unsigned short *)p.out;
                 const int ldo_ = (int)p.ldo;
 #pragma unroll
@@ -430,11 +455,11 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int ET, int NJ, bool GATE, bool OBF, bool ADD = false>
+template <int ET, int NJ, bool GATE, bool OBF, bool ADD = false, bool GF = false>
 int ring_launch(const GemmP &p, hipStream_t st)
 {
     static int state = 0, cus = 256;                         // 0 unknown, 1 usable, -1 the device refuses 160 KiB of LDS per workgroup
-    auto kern = gemm_ring_kernel<ET, NJ, GATE, OBF, ADD>;
+    auto kern = gemm_ring_kernel<ET, NJ, GATE, OBF, ADD, GF>;
     if (state == 0) {
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -454,9 +479,10 @@ int ring_launch(const GemmP &p, hipStream_t st)
 
 // shape rules shared by both operand types; returns the accumulator columns per wave (2: 256-column tiles, 1: 128-column tiles)
 // the problem should run with, or 0 if the ring kernel does not take it
-int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32)
+int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32, bool gate_fwd = false)
 {
-    if (g_ring == 0 || groups != 1 || p.use_table || p.in2 || p.out2) return 0;
+    if (g_ring == 0 || groups != 1 || p.use_table || p.in2) return 0;
+    if (gate_fwd ? !(p.out2 && p.out3) : (p.out2 != nullptr)) return 0;
     if (p.M % RT || (p.K & 15) || p.K < 16) return 0;
     if (p.seg_mode == LDM_SEG_K && p.nseg > 1 && (p.seg_len & 15)) return 0;
     if (p.lda * 4 * RT >= (1ll << 31) || p.ldw * 4 * RT >= (1ll << 31)) return 0;
@@ -479,7 +505,7 @@ int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32)
         const long long rounds = (tiles + cus - 1) / cus;
         return tiles * 4 >= (long long)cus * 3 && tiles * 100 >= rounds * cus * 88;
     };
-    if (!any && p.K < 128) return 0;
+    if (!any && p.K < (fp32 ? 128 : 64)) return 0;            // bf16: 4 steps (measured: the gated forward at C = 128 runs 1.5x the stream kernel)
     if (!any && fp32 && p.addend && p.K < 384) return 0;
     if (gate) return (unit % 128 == 0 && fills(mt * (p.N / 128))) ? 2 : 0;
     if (unit % 256 == 0 && fills(mt * (p.N / 256))) return 2;
@@ -503,6 +529,14 @@ int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipSt
     if (ring_shape(p, groups, false, out_bf16, false) != 2) return 0;
     if (out_bf16) return ring_launch<1, 2, false, true>(p, st);
     return p.addend ? ring_launch<1, 2, false, false, true>(p, st) : ring_launch<1, 2, false, false, false>(p, st);
+}
+
+// bf16 ReGLU forward with saved pre-activations (ldm_gemm_bf16_gate_fwd): returns 1 if the ring kernel launched
+int ldm_gemm_ring_dispatch_bf16_gate(const GemmP &p, int groups, hipStream_t st)
+{
+    if (!p.out2 || !p.out3 || p.addend || p.ldo % 4 || (((size_t)p.out | (size_t)p.out2 | (size_t)p.out3) & 7)) return 0;
+    if (ring_shape(p, groups, true, false, false, true) != 2) return 0;
+    return ring_launch<1, 2, true, false, false, true>(p, st);
 }
 
 // exact fp32 (ldm_gemm_f32: rows in, rows out, plain or gated): returns 1 if the ring kernel launched

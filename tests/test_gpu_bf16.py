@@ -322,3 +322,35 @@ def test_gemm_bf16_fused_gate_forward_and_backward(gpu_device, M, C, nseg):
     assert rel_l2(da.double().cpu(), (dh64 * torch.relu(b_pre.double())).cpu()) < 3e-3
     assert rel_l2(db.double().cpu(), (dh64 * a_pre.double() * (b_pre.double() > 0)).cpu()) < 3e-3
     assert rel_l2(da.double().cpu(), da_ref.double().cpu()) < 6e-3 and rel_l2(db.double().cpu(), db_ref.double().cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("M,C,nseg", [(2048, 128, 3), (4096, 256, 2), (1024, 512, 1), (8192, 128, 1)])
+def test_gemm_bf16_gate_forward_ring_kernel_bit_identical_to_stream_kernel(gpu_device, M, C, nseg):
+    """ldm_gemm_bf16_gate_fwd (hid = a relu(b) + both pre-activations, bf16) on the gated ring instance == the stream kernel's, bit
+    for bit, also with many tiles per workgroup (schedule 3); and right against float64."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + C + nseg)
+    N = nseg * C
+    x = bf(torch.randn(M, C, generator=g)).cuda()
+    wa = [bf(torch.randn(C, C, generator=g) / C ** 0.5).cuda() for _ in range(nseg)]
+    wb = [bf(torch.randn(C, C, generator=g) / C ** 0.5).cuda() for _ in range(nseg)]
+    ba = [torch.randn(C, generator=g).cuda() for _ in range(nseg)]
+    bb = [torch.randn(C, generator=g).cuda() for _ in range(nseg)]
+    outs = {}
+    old = ops.gemm_ring(1)
+    try:
+        for mode in (0, 2, 3):
+            ops.gemm_ring(mode)
+            hid, a_pre, b_pre = (torch.full((M, N), float("nan"), device=gpu_device, dtype=BF) for _ in range(3))
+            ops.gemm_bf16_gate_fwd(x, M, N, C, wa, wb, hid, biases_a=ba, biases_b=bb, a_pre=a_pre, b_pre=b_pre)
+            outs[mode] = (hid, a_pre, b_pre)
+    finally:
+        ops.gemm_ring(old)
+    for mode in (2, 3):
+        for k in range(3):
+            assert torch.equal(outs[0][k], outs[mode][k]), (mode, k)
+    xd = x.double()
+    a_ref = torch.cat([xd @ w.double().t() + b_.double() for w, b_ in zip(wa, ba)], 1)
+    b_ref = torch.cat([xd @ w.double().t() + b_.double() for w, b_ in zip(wb, bb)], 1)
+    assert rel_l2(outs[2][1].double().cpu(), a_ref.cpu()) < 3e-3 and rel_l2(outs[2][2].double().cpu(), b_ref.cpu()) < 3e-3
+    assert rel_l2(outs[2][0].double().cpu(), (a_ref * torch.relu(b_ref)).cpu()) < 4e-3

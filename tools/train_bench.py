@@ -15,7 +15,8 @@ from ldm_image_generator_amd.unet import UNet  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--latent", type=int, default=64)
-ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2, help="untimed steps before the timed ones (the first two grow the caching allocator)")
 ap.add_argument("--gemm-variant", type=int, default=1, help="1 = exact-fp32 stream schedule, 2 = bf16x3 split consumer")
 ap.add_argument("--fused-adamw", type=int, default=1, help="1 (default, as bench.py): torch.optim.AdamW(fused=True); 0: the foreach default")
 ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="operand precision of the training step (train.set_precision)")
@@ -30,7 +31,8 @@ ltrain.set_precision(net, args.precision)
 ddpm = DDPM(model=net)
 opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4, fused=bool(args.fused_adamw))
 x = torch.randn(args.batch, 8, args.latent, args.latent, generator=torch.Generator().manual_seed(0)).to(dev)
-ldist.train_step(ddpm, opt, x, 0, 1)
+for i in range(args.warmup):
+    ldist.train_step(ddpm, opt, x, 0, 1)
 torch.cuda.synchronize()
 ops.prof_enable(True)
 t0 = time.perf_counter()
