@@ -10,7 +10,8 @@ bilinear RGB accumulation are one fused HBM-bound kernel per stage.
 ``Encoder`` (latent pre-encoding for train_ldm.py) reuses the same kernels.  SURVEY 8f.4 (VAE training) is started
 with its integer part: ``VectorQuantizer`` (quantize with the reference's indices, embed, the two-sided L1 loss with gradients) and
 ``VAE.calclate_loss``; ``Encoder`` and ``Decoder`` are differentiable (``vae_train.py``: parameter gradients and input gradients,
-pinned against the reference's autograd), so the VAE objective trains end to end; the ``Discriminator`` is not provided.
+pinned against the reference's autograd), so the VAE objective trains end to end.  ``Discriminator`` (train_vae.py's adversarial
+term) runs forward and backward on the same kernels, its 48-channel stages carried at 64 zero-padded columns.
 """
 import torch
 import torch.nn as nn
@@ -276,6 +277,38 @@ class VAE(nn.Module):
     @torch.no_grad()
     def decode(self, z):
         return self.decoder(z)
+
+
+class Discriminator(nn.Module):
+    """vae.py:134-171: the multi-scale critic of train_vae.py (adversarial term + its own hinge loss).  Same constructor, parameter
+    names and registration order as the reference (``input_layer``, ``stages.*``, ``downsamples.*``, ``early_exits.*``); both
+    methods are differentiable w.r.t. the parameters and the fake batch (``vae_train.DiscriminatorFunction``)."""
+
+    def __init__(self, input_channels=3, channels=[32, 48, 48, 96], stages=[2, 2, 2, 2], stem_size=1):
+        super().__init__()
+        if stem_size != 1:
+            raise NotImplementedError("Discriminator: stem_size != 1 is not on the HIP path")
+        self.input_layer = nn.Conv2d(input_channels, channels[0], stem_size, stem_size, 0)
+        self.stages = nn.ModuleList([ResStack(c, l) for c, l in zip(channels, stages)])
+        self.early_exits = nn.ModuleList([])
+        self.downsamples = nn.ModuleList([])
+        for i, c in enumerate(channels):
+            if i == len(self.stages) - 1:
+                self.downsamples.append(nn.Identity())
+            else:
+                self.downsamples.append(nn.Conv2d(c, channels[i + 1], 2, 2, 0))
+            self.early_exits.append(nn.Conv2d(c, 1, 1, 1, 0))
+
+    def _run(self, fake_x, real_x):
+        from .vae_train import DiscriminatorFunction
+        return DiscriminatorFunction.apply(self, fake_x, real_x, *[p for p in self.parameters() if p.requires_grad])
+
+    def calclate_logit_and_feature_matching(self, fake_x, real_x):
+        real_x.requires_grad = False                      # as the reference (vae.py:150)
+        return self._run(fake_x, real_x)
+
+    def calclate_logit(self, fake_x):
+        return self._run(fake_x, None)[0]
 
 
 def to_uint8_images(img):

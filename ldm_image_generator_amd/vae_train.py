@@ -252,3 +252,151 @@ class ToRowsFunction(torch.autograd.Function):
         out = torch.empty(b, c, h, w, device=g.device, dtype=torch.float32)
         ops.nhwc_to_nchw(g.contiguous().float(), out, b, c, h * w)
         return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# Discriminator (vae.py:134-171): stem 1x1, ResStacks at 32 / 48 / 48 / 96 channels, Conv 2x2 stride 2 between stages, and
+# one 1-channel "early exit" per stage whose spatial mean is summed into the logit.
+# ------------------------------------------------------------------------------------------------------
+def _pad32(c):
+    """row width a c-channel layer is carried at: the GEMM family works on 32-column multiples, and the dense 3x3 conv on
+    Cin % 32 == 0, so the 48-channel stages run at 64 with zero weights / biases in the 16 extra channels.  Those channels stay
+    exactly zero through conv + leaky ReLU + skip, and their (meaningless) weight gradients are sliced away."""
+    return c if c % 32 == 0 else (c + 63) // 64 * 64
+
+
+class _PaddedConv:
+    """zero-padded stand-in for an nn.Conv2d(c, c', k): ``weight`` [P(c'), P(c), k, k], ``bias`` [P(c')]."""
+
+    def __init__(self, conv):
+        w, b = conv.weight.detach(), conv.bias.detach()
+        co, ci = w.shape[0], w.shape[1]
+        pco, pci = _pad32(co), _pad32(ci)
+        self.real = conv
+        if (pco, pci) == (co, ci):
+            self.weight, self.bias = w, b
+        else:
+            self.weight = torch.zeros(pco, pci, w.shape[2], w.shape[3], device=w.device, dtype=torch.float32)
+            self.weight[:co, :ci] = w
+            self.bias = torch.zeros(pco, device=w.device, dtype=torch.float32)
+            self.bias[:co] = b
+
+    def unpad(self, grads, out):
+        """move this layer's gradients (keyed by the padded tensors) onto the real parameters."""
+        co, ci = self.real.weight.shape[0], self.real.weight.shape[1]
+        if self.weight in grads:
+            out[self.real.weight] = grads[self.weight][:co, :ci].contiguous()
+            out[self.real.bias] = grads[self.bias][:co].contiguous()
+
+
+class _PaddedBlock:
+    def __init__(self, blk):
+        self.c1, self.c2 = _PaddedConv(blk.c1), _PaddedConv(blk.c2)
+
+
+class DiscriminatorFunction(torch.autograd.Function):
+    """``Discriminator.calclate_logit`` (``real is None``) and ``calclate_logit_and_feature_matching`` (vae.py:149-171).
+    With a real batch the two batches run as ONE batch of 2B samples (every layer is per-sample), the fake half feeding the logit
+    and both halves the per-stage L1 feature distance.  Returns (logit, feat_loss); feat_loss is a zero scalar without ``real``."""
+
+    @staticmethod
+    def forward(fctx, disc, fake, real, *params):
+        from torch import nn
+        dev = fake.device
+        nf = fake.shape[0]
+        x = fake.contiguous().float() if real is None else torch.cat([fake.float(), real.float()], 0).contiguous()
+        b, cin, h, w = x.shape
+        c0 = disc.input_layer.weight.shape[0]
+        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x, w2d(disc.input_layer), disc.input_layer.bias.detach(), rows, b, cin, h * w, c0)
+        logit = torch.zeros(1, device=dev, dtype=torch.float32)
+        feat = torch.zeros(1, device=dev, dtype=torch.float32)
+        tape = []
+        for stage, down, exit_conv in zip(disc.stages, disc.downsamples, disc.early_exits):
+            rec = dict(blocks=[], pblocks=[_PaddedBlock(blk) for blk in stage.seq], shape=(b, h, w), down=None)
+            for pblk in rec["pblocks"]:
+                rows = _resblock_forward(pblk, rows, (b, h, w), rec["blocks"])
+            m, cp = rows.shape
+            c = exit_conv.weight.shape[1]
+            mf = nf * h * w                                                    # rows of the fake half
+            if real is not None:                                              # (fake_x - real_x).abs().mean() over the c real channels
+                part = torch.empty(1, device=dev, dtype=torch.float32)
+                ops.l1_loss(rows[:mf], rows[mf:], part)
+                feat.add_(part, alpha=cp / c)                                   # scalar bookkeeping only (the padded zeros add 0 to the sum)
+            # c(fake_x).mean(): the 1-channel 1x1 conv through the NHWC -> NCHW head kernel, then one column sum
+            w_exit = torch.zeros(cp, 1, device=dev, dtype=torch.float32)
+            w_exit[:c, 0] = exit_conv.weight.detach().reshape(-1)
+            e = torch.empty(nf, 1, h, w, device=dev, dtype=torch.float32)
+            ops.head_nchw(rows[:mf], w_exit, exit_conv.bias.detach(), e, nf, cp, h * w, 1)
+            logit.add_(ops.colsum(e, mf, 1), alpha=1.0 / mf)
+            rec.update(rows=rows, exit=exit_conv, w_exit=w_exit, c=c)
+            if not isinstance(down, nn.Identity):                              # Conv2d(c, c', 2, 2): space-to-depth + GEMM
+                pd = _PaddedConv(down)
+                pco, pci = pd.weight.shape[0], pd.weight.shape[1]
+                packed = pd.weight.permute(0, 2, 3, 1).reshape(pco, 4 * pci).contiguous()           # [co][(dy, dx, ci)]
+                s2d = ops.space_to_depth2(rows, b, h // 2, w // 2, cp)
+                h, w = h // 2, w // 2
+                rows = torch.empty(b * h * w, pco, device=dev, dtype=torch.float32)
+                ops.gemm(s2d, b * h * w, pco, 4 * pci, [packed], rows, biases=[pd.bias])
+                rec["down"] = dict(pd=pd, packed=packed, s2d=s2d)
+            tape.append(rec)
+        fctx.disc, fctx.tape, fctx.x, fctx.params, fctx.nf, fctx.has_real = disc, tape, x, params, nf, real is not None
+        return logit.reshape(()), feat.reshape(())
+
+    @staticmethod
+    def backward(fctx, glogit, gfeat):
+        disc, tape, x, nf = fctx.disc, fctx.tape, fctx.x, fctx.nf
+        dev = x.device
+        pg, grads = {}, {}                              # gradients keyed by padded stand-ins / by the real parameters
+        glogit = glogit.reshape(1).contiguous().float()
+        gfeat = gfeat.reshape(1).contiguous().float()
+        drows = None
+        for rec in reversed(tape):
+            b, h, w = rec["shape"]
+            rows, cp, c = rec["rows"], rec["rows"].shape[1], rec["c"]
+            m, mf = rows.shape[0], nf * h * w
+            if rec["down"] is not None:
+                pd, packed, s2d = rec["down"]["pd"], rec["down"]["packed"], rec["down"]["s2d"]
+                pco, pci = pd.weight.shape[0], pd.weight.shape[1]
+                dr = _Rows(drows)
+                dwp = grad_weight_rows(dr, _Rows(s2d), drows.shape[0])                          # [co][(dy, dx, ci)]
+                pg[pd.weight] = dwp.reshape(pco, 2, 2, pci).permute(0, 3, 1, 2).contiguous()
+                pg[pd.bias] = dr.colsum().clone()
+                pd.unpad(pg, grads)
+                fine = torch.empty(m, pci, device=dev, dtype=torch.float32)
+                ops.gemm(drows, drows.shape[0], 4 * pci, pco, [packed.t().contiguous()], fine, ldo=pci, o_mode=ops.O_CONVT2X2,
+                         out_hw=(h // 2, w // 2), cout=pci)                                   # depth-to-space in the epilogue
+                drows = fine
+            else:
+                drows = torch.zeros(m, cp, device=dev, dtype=torch.float32)
+            # early exit: logit += mean_p (rows[p] . w + b) over the fake half
+            dout = (glogit * (1.0 / mf)).expand(mf).contiguous().reshape(nf, 1, h, w)
+            dexit = torch.empty(mf, cp, device=dev, dtype=torch.float32)
+            dw_e = torch.empty(cp, 1, device=dev, dtype=torch.float32)
+            db_e = torch.empty(1, device=dev, dtype=torch.float32)
+            ops.head_bwd(rows[:mf], rec["w_exit"], dout, dexit, dw_e, db_e, nf, cp, h * w, 1)
+            ops.add_(drows[:mf], dexit)
+            grads[rec["exit"].weight] = dw_e[:c, 0].reshape(rec["exit"].weight.shape).contiguous()
+            grads[rec["exit"].bias] = db_e
+            if fctx.has_real:                                                 # d mean|fake - real| (x cp / c: the mean is over c channels)
+                gs = gfeat * (cp / c)
+                dl = torch.empty(mf, cp, device=dev, dtype=torch.float32)
+                ops.l1_loss_bwd(rows[:mf], rows[mf:], gs, dl)
+                ops.add_(drows[:mf], dl)
+                ops.l1_loss_bwd(rows[mf:], rows[:mf], gs, dl)
+                ops.add_(drows[mf:], dl)
+            for blk_rec, pblk in zip(reversed(rec["blocks"]), reversed(rec["pblocks"])):
+                drows = _resblock_backward(blk_rec, drows, (b, h, w), pg)
+                pblk.c1.unpad(pg, grads)
+                pblk.c2.unpad(pg, grads)
+        b, cin, h0, w0 = x.shape
+        c0 = disc.input_layer.weight.shape[0]
+        dw0 = torch.empty(c0, cin, device=dev, dtype=torch.float32)
+        ops.stem_bwd(x, drows, dw0, b, cin, h0 * w0, c0)
+        grads[disc.input_layer.weight] = dw0.reshape(disc.input_layer.weight.shape)
+        grads[disc.input_layer.bias] = ops.colsum(drows, drows.shape[0], c0)
+        dfake = None
+        if fctx.needs_input_grad[1]:                                          # real_x.requires_grad = False (vae.py:150)
+            dfake = torch.empty(nf, cin, h0, w0, device=dev, dtype=torch.float32)
+            ops.head_nchw(drows[:nf * h0 * w0], w2d(disc.input_layer).contiguous(), None, dfake, nf, c0, h0 * w0, cin)
+        return (None, dfake, None) + tuple(grads.get(p) for p in fctx.params)

@@ -389,6 +389,51 @@ def encoder_state_shapes(input_channels=3, latent_channels=8, channels=(64, 128,
     return out
 
 
+def discriminator_features(sd, x, stages=(2, 2, 2, 2), prefix=""):
+    """vae.py:149-171 (both ``calclate_logit*`` walk the same layers): the per-stage feature maps after each ResStack and the
+    per-stage early-exit maps c(x) (1 channel); Conv2d(c, c', 2, 2) between stages."""
+    p = prefix
+    y = _pointwise(x, sd[p + "input_layer.weight"], sd[p + "input_layer.bias"])
+    feats, exits = [], []
+    for s, nblk in enumerate(stages):
+        for k in range(nblk):
+            y = res_block(sd, "%sstages.%d.seq.%d." % (p, s, k), y)
+        feats.append(y)
+        exits.append(_pointwise(y, sd["%searly_exits.%d.weight" % (p, s)], sd["%searly_exits.%d.bias" % (p, s)]))
+        if s < len(stages) - 1:
+            y = F.conv2d(y, sd["%sdownsamples.%d.weight" % (p, s)], sd["%sdownsamples.%d.bias" % (p, s)], stride=2)
+    return feats, exits
+
+
+def discriminator_logit(sd, fake, stages=(2, 2, 2, 2), prefix=""):
+    """vae.py:163-171: sum over stages of the spatial (and batch) mean of the early exit."""
+    return sum(e.mean() for e in discriminator_features(sd, fake, stages, prefix)[1])
+
+
+def discriminator_logit_and_feature_matching(sd, fake, real, stages=(2, 2, 2, 2), prefix=""):
+    """vae.py:149-161: the logit of the fake batch and sum over stages of mean |feature(fake) - feature(real)|."""
+    ff, fe = discriminator_features(sd, fake, stages, prefix)
+    rf, _ = discriminator_features(sd, real, stages, prefix)
+    return sum(e.mean() for e in fe), sum((a - b).abs().mean() for a, b in zip(ff, rf))
+
+
+def discriminator_state_shapes(input_channels=3, channels=(32, 48, 48, 96), stages=(2, 2, 2, 2), prefix=""):
+    """registration order of vae.py:135-147: input_layer, stages, then per stage (downsample, early_exit) -- ``downsamples`` and
+    ``early_exits`` are appended alternately but live in separate ModuleLists, so state_dict lists all early_exits first."""
+    out = {}
+    p = prefix
+    _conv_keys(out, p + "input_layer.", channels[0], input_channels)
+    for s, c in enumerate(channels):
+        for k in range(stages[s]):
+            _conv_keys(out, "%sstages.%d.seq.%d.c1." % (p, s, k), c, c, 3)
+            _conv_keys(out, "%sstages.%d.seq.%d.c2." % (p, s, k), c, c, 3)
+    for s, c in enumerate(channels):
+        _conv_keys(out, "%searly_exits.%d." % (p, s), 1, c)
+    for s in range(len(channels) - 1):
+        _conv_keys(out, "%sdownsamples.%d." % (p, s), channels[s + 1], channels[s], 2)
+    return out
+
+
 def to_uint8_hwc(img):
     """sample_ldm.py:75-77: clamp(-1,1) -> *127.5+127.5 -> uint8 TRUNCATION -> HWC."""
     img = torch.clamp(img, -1, 1)

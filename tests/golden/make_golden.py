@@ -407,6 +407,35 @@ def vae_bwd_cases():
     save("vae_bwd", **arrs)
 
 
+def discriminator_cases():
+    """Discriminator (vae.py:134-171, default widths 32 / 48 / 48 / 96) through the reference's autograd: ``calclate_logit`` with
+    the generator-side hinge of train_vae.py:113 (relu(-logit)) and ``calclate_logit_and_feature_matching`` (logit + feature
+    distance); every parameter gradient (norm + a corner) and the gradient at the fake batch."""
+    arrs = {}
+    for tag in ("logit", "fm"):
+        disc = load_formula(ref_vae.Discriminator(), salt=3)
+        fake = g("disc.fake" + tag, (2, 3, 32, 32)).clone().requires_grad_()
+        real = g("disc.real" + tag, (2, 3, 32, 32))
+        if tag == "logit":
+            logit = disc.calclate_logit(fake)
+            loss = torch.nn.functional.relu(1 - logit) * 0.5 + logit * 0.25          # both sides of the hinge stay live
+            arrs["logit_" + tag] = logit.detach()
+        else:
+            logit, feat = disc.calclate_logit_and_feature_matching(fake, real.clone())
+            loss = logit * 0.5 + feat
+            arrs["logit_" + tag], arrs["feat_" + tag] = logit.detach(), feat.detach()
+        loss.backward()
+        arrs["fake_" + tag], arrs["real_" + tag], arrs["dfake_" + tag] = fake.detach(), real, fake.grad
+        names = []
+        for k, p_ in disc.named_parameters():
+            if p_.grad is not None:
+                names.append(k)
+                arrs["gradnorm_%s_%s" % (tag, k)] = p_.grad.double().norm()
+                arrs["gradslice_%s_%s" % (tag, k)] = p_.grad.reshape(p_.grad.shape[0], -1)[-32:, -96:].clone()   # the LAST channels
+        arrs["names_" + tag] = np.array(names)
+    save("discriminator", **arrs)
+
+
 def vq_cases():
     """VectorQuantizer (vae.py:7-26) on its default codebook size (8192 x 8): indices, embedding rows, the two-sided L1 loss and its
     gradients, plus VAE.calclate_loss's forward on a tiny encoder / decoder with the noise replayed.  The codebook gets three
@@ -456,6 +485,9 @@ if __name__ == "__main__":
     if "--encoder-only" in sys.argv:
         encoder_cases()
         sys.exit(0)
+    if "--discriminator-only" in sys.argv:
+        discriminator_cases()
+        sys.exit(0)
     if "--decoder-bwd-only" in sys.argv:
         decoder_bwd_cases()
         vae_bwd_cases()
@@ -471,4 +503,5 @@ if __name__ == "__main__":
     encoder_cases()
     decoder_bwd_cases()
     vae_bwd_cases()
+    discriminator_cases()
     vq_cases()

@@ -259,3 +259,29 @@ def test_encoder_tiny_and_full():
     assert sum(int(np.prod(s)) for s in shapes.values()) == 12714888
     with torch.no_grad():
         assert rel_l2(O.vae_encode(O.formula_state(shapes), T(g["x"])), T(g["z"])) < TOL
+
+
+def test_discriminator_logit_feature_matching_and_gradients():
+    """vae.py:134-171 through the oracle's restatement + torch autograd vs the reference's own autograd (golden ``discriminator``)."""
+    g = load_golden("discriminator")
+    shapes = O.discriminator_state_shapes()
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 569764
+    for tag in ("logit", "fm"):
+        sd = {k: v.clone().requires_grad_() for k, v in O.formula_state(shapes, salt=3).items()}
+        fake = T(g["fake_" + tag]).clone().requires_grad_()
+        if tag == "logit":
+            logit = O.discriminator_logit(sd, fake)
+            loss = torch.relu(1 - logit) * 0.5 + logit * 0.25
+        else:
+            logit, feat = O.discriminator_logit_and_feature_matching(sd, fake, T(g["real_" + tag]))
+            assert abs(float(feat) - float(g["feat_" + tag])) < TOL * abs(float(g["feat_" + tag]))
+            loss = logit * 0.5 + feat
+        assert abs(float(logit) - float(g["logit_" + tag])) < 1e-6
+        loss.backward()
+        assert rel_l2(fake.grad, T(g["dfake_" + tag])) < 1e-5
+        for k in g["names_" + tag]:
+            k = str(k)
+            ref = float(g["gradnorm_%s_%s" % (tag, k)])
+            assert abs(float(sd[k].grad.double().norm()) - ref) < 1e-5 * ref + 1e-12, k
+            sl = sd[k].grad.reshape(sd[k].shape[0], -1)[-32:, -96:]
+            assert rel_l2(sl, T(g["gradslice_%s_%s" % (tag, k)])) < 1e-5, k
