@@ -382,6 +382,9 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
     p.use_table = d->w_table ? 1 : 0;
     p.wide_ok = d->o_mode == LDM_O_ROWS && ldm_aligned16(d->out) && d->ldo % 4 == 0 && d->o_gstride % 4 == 0 &&
                 (!d->addend || (ldm_aligned16(d->addend) && d->ldadd % 4 == 0));
+    p.scat_ok = d->o_mode != LDM_O_ROWS && ldm_aligned16(d->out) && d->ldo % 4 == 0 && d->o_gstride % 4 == 0 && d->M < (1 << 23) &&
+                (!d->addend || (ldm_aligned16(d->addend) && d->ldadd % 4 == 0)) && (d->o_mode != LDM_O_CONVT2X2 || d->Cout % 4 == 0);
+    p.inv_ow = d->o_mode != LDM_O_ROWS ? 1.0f / (float)d->OW : 0.f;
     if (d->w_table) {
         LDM_REQUIRE(groups <= LDM_MAX_TABLE, "ldm_gemm_f32: pointer-table mode supports at most %d groups", LDM_MAX_TABLE);
         for (int i = 0; i < groups; ++i) {

@@ -26,6 +26,8 @@ struct GemmP {
     long long a_gstride, w_gstride, o_gstride, b_gstride;
     int use_table;                              // pointer-table mode: per-group weights / biases below
     int wide_ok;                                // rows output (and addend) 16-byte addressable: the stream kernel may use its wide epilogue
+    int scat_ok;                                // scatter output (convT 2x2 / up x2) 16-byte addressable and M < 2^23: wide scatter epilogue
+    float inv_ow;                               // 1 / OW (row -> (image row, x) by reciprocal multiply in that epilogue)
     const float *wtab[LDM_MAX_TABLE];
     const float *btab[LDM_MAX_TABLE];
     // bf16 training fusions of the wide epilogue (ldm_gemm_bf16_gate_fwd / _bwd), all bf16 [M, ldo] like `out`:
@@ -319,7 +321,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, bool OBF, int ACT>
+template <int WM, int WN, int TM, int TN, bool GATE, bool OBF, int ACT, bool SCAT = false>
 __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int n0, int g, int wm, int wn,
                                                    const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre,
                                                    const WideLane<TN> &wl, float *scratch /* stage base + wave * 256 */)
@@ -338,6 +340,15 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
     float *wr = scratch + wl.wr_off;
     const float *rd = scratch + wl.rd_off;
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    // scatter outputs (SCAT): coarse row m = q1 * OW + x lands on fine rows 4 OW q1 + 2 x + {0, 1, 2 OW, 2 OW + 1} -- all four for
+    // up x2, the one its column quadrant q4 = n / Cout names for convT 2x2 (a lane's four columns share q4: Cout % 4 == 0)
+    const int scol = g * (int)p.o_gstride + n0 + wn * TN * 32 + 4 * wl.cc;
+    int s_q4 = 0, s_col = scol;
+    if (SCAT && p.o_mode == LDM_O_CONVT2X2) {
+        const int nloc = n0 + wn * TN * 32 + 4 * wl.cc;
+        s_q4 = nloc / p.Cout;
+        s_col = g * (int)p.o_gstride + nloc - s_q4 * p.Cout;
+    }
     // passes over the tile: 1, or 3 for the gate forward that also saves its pre-activations (hid, a, b)
     const int npass = (GATE && OBF && p.out2 != nullptr) ? 3 : 1;
     const bool gate_bwd = !GATE && OBF && p.in2 != nullptr;
@@ -392,7 +403,34 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
                     for (int cix = 0; cix < 4; ++cix) v[cix] += pre[im][(4 * k + cix) >> 4][(4 * k + cix) & 15];
                 }
                 const int roff = im * 32 + k * RPI;
-                if (full || row0 + roff < p.M) {
+                if constexpr (SCAT) {
+                    const int m = row0 + roff;
+                    if (full || m < p.M) {
+                        int q1 = (int)((float)m * p.inv_ow);                      // exact after one correction each way (m < 2^23)
+                        int xx = m - q1 * p.OW;
+                        q1 += xx >= p.OW ? 1 : (xx < 0 ? -1 : 0);
+                        xx = m - q1 * p.OW;
+                        const long long orow0 = 4ll * p.OW * q1 + 2 * xx;
+                        const int ox2 = 2 * p.OW;
+                        if (p.o_mode == LDM_O_UP2) {
+                            f32x4 ad[4];
+                            if (p.addend) {
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) ad[d] = *(const f32x4 *)(p.addend + (orow0 + (d >> 1) * ox2 + (d & 1)) * p.ldadd + scol);
+                            }
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                f32x4 o = v;
+                                if (p.addend) o += ad[d];
+                                *(f32x4 *)(p.out + (orow0 + (d >> 1) * ox2 + (d & 1)) * p.ldo + scol) = o;
+                            }
+                        } else {
+                            const long long orow = orow0 + (s_q4 >> 1) * ox2 + (s_q4 & 1);
+                            if (p.addend) v += *(const f32x4 *)(p.addend + orow * p.ldadd + s_col);
+                            *(f32x4 *)(p.out + orow * p.ldo + s_col) = v;
+                        }
+                    }
+                } else if (full || row0 + roff < p.M) {
                     if constexpr (OBF) {
                         if (gate_bwd) {
                             float da[4], db[4];
@@ -419,11 +457,15 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, bool OBF = false>
+template <int WM, int WN, int TM, int TN, bool GATE, bool OBF = false, bool SCAT = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int n0, int g, int wm, int wn,
                                                    const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre, const WideLane<TN> &wl, float *scratch)
 {
-    if constexpr (GATE) {
+    if constexpr (SCAT) {
+        if (p.act == LDM_ACT_RELU) gemm_epilogue_wide_act<WM, WN, TM, TN, false, false, LDM_ACT_RELU, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);
+        else if (p.act == LDM_ACT_LRELU) gemm_epilogue_wide_act<WM, WN, TM, TN, false, false, LDM_ACT_LRELU, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);
+        else gemm_epilogue_wide_act<WM, WN, TM, TN, false, false, LDM_ACT_NONE, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);
+    } else if constexpr (GATE) {
         gemm_epilogue_wide_act<WM, WN, TM, TN, GATE, OBF, LDM_ACT_GATE>(p, acc, m0, n0, g, wm, wn, c, pre, use_pre, wl, scratch);
     } else {
         if (p.act == LDM_ACT_RELU) gemm_epilogue_wide_act<WM, WN, TM, TN, GATE, OBF, LDM_ACT_RELU>(p, acc, m0, n0, g, wm, wn, c, pre, use_pre, wl, scratch);

@@ -86,11 +86,12 @@ __device__ __forceinline__ void mfma6(const Split3 &a, const Split3 &b, f32x16 &
 // ET = 1: both operands are bf16 (rows of 128 B = 64 k), one v_mfma_f32_32x32x16_bf16 per fragment pair; the loader, the LDS
 // ring and the swizzle are unchanged because they only ever move 16-byte chunks of 128-byte rows -- the host passes K, lda,
 // ldw and the group strides in units of 4 bytes (two bf16).  OBF: the (wide) epilogue rounds the result to bf16 (RNE).
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false, bool SCAT = false>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     static_assert(ET == 0 || SPLIT == 0, "bf16 operands: no split consumer");
     static_assert(!OBF || WIDE, "bf16 output goes through the wide epilogue");
+    static_assert(!SCAT || (WIDE && !GATE && !OBF && ET == 0), "wide scatter epilogue: plain fp32 instances only");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr int A_F4 = BM / 32, B_F4 = NB / 32;
@@ -414,21 +415,21 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
             mma(fa1, fb1);
         }
         if constexpr (WIDE)      // scratch: this wave's slices of the stage the tile's last step has just released
-            gemm_epilogue_wide<WM, WN, TM, TN, GATE, OBF>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
+            gemm_epilogue_wide<WM, WN, TM, TN, GATE, OBF, SCAT>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
         else
             gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
         ++s;
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false, bool SCAT = false>
 int launch_stream(const GemmP &p, int groups, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
     static int slots = 0;
-    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE, ET, OBF>;
+    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE, ET, OBF, SCAT>;
     if (slots == 0) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int dev = 0, cus = 256;
@@ -494,6 +495,13 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
             return launch_stream_w<2, 2, 2, 2, false, LDM_A_CONV3X3>(p, groups, st);
         if (unit % 64 == 0) return launch_stream_w<2, 2, 2, 1, false, LDM_A_CONV3X3>(p, groups, st);
         return launch_stream_w<4, 1, 1, 1, false, LDM_A_CONV3X3>(p, groups, st);
+    }
+    if (p.o_mode != LDM_O_ROWS && p.scat_ok && g_wide && p.M > 32) {
+        // convT 2x2 / up x2: the wide epilogue with scattered row addresses (16-byte stores; the direct one is 4-byte stores behind
+        // three integer divisions per accumulator element)
+        if (unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512)
+            return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, 0, true, 0, false, true>(p, groups, st);
+        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, true, 0, false, true>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch_stream_w<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
     // 128x128 tiles where N allows and the tile count still fills the chip (two workgroups per CU): a third fewer LDS-DMA instructions per MFMA (with the wide

@@ -165,6 +165,47 @@ def test_upsample_conv_skip(ops, gpu_device):
     assert rel_l2(got, ref) < KTOL
 
 
+@pytest.mark.parametrize("mode,B,H,W,Cin,Cout,with_add,act", [
+    ("up2", 2, 4, 4, 128, 64, True, 0),          # UNet decoder s3 -> s2 shape class: OW = 4 < rows per store instruction
+    ("up2", 3, 5, 7, 64, 128, True, 0),          # ragged M (105 rows), 64-column strips
+    ("up2", 8, 32, 32, 256, 128, True, 0),       # 128x128 tiles (>= 512 of them)
+    ("up2", 1, 6, 10, 64, 64, False, 1),
+    ("convt", 2, 3, 5, 64, 64, False, 0),        # N = 256, Cout = 64: a 128-column tile spans two quadrants
+    ("convt", 1, 8, 8, 128, 32, True, 3),        # Cout = 32: four quadrants per 128 columns
+    ("convt", 16, 32, 32, 128, 128, False, 0),   # 128x128 tiles
+])
+def test_scatter_outputs_wide_epilogue_bit_identical_to_direct(ops, gpu_device, mode, B, H, W, Cin, Cout, with_add, act):
+    """up x2 / convT 2x2 outputs through the 16-byte scatter epilogue == the direct 4-byte one (same arithmetic, same order), and both
+    against fp64."""
+    o = ops
+    M = B * H * W
+    x = rnd(B, Cin, H, W)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda()
+    add = rnd(B * 4 * H * W, Cout, seed=3).cuda() if with_add else None
+    if mode == "up2":
+        w, b = rnd(Cout, Cin, seed=1, scale=Cin ** -0.5), rnd(Cout, seed=2)
+        wp, N, kw = w.cuda(), Cout, dict(o_mode=o.O_UP2, out_hw=(H, W))
+        ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double().reshape(Cout, Cin, 1, 1), b.double())
+    else:
+        w, b = rnd(Cin, Cout, 2, 2, seed=1, scale=Cin ** -0.5), rnd(Cout, seed=2)
+        wp, N = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).contiguous().cuda(), 4 * Cout
+        kw = dict(ldo=Cout, ldadd=Cout, o_mode=o.O_CONVT2X2, out_hw=(H, W), cout=Cout)
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    ref = F.relu(ref) if act == o.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == o.ACT_LRELU else ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout) + (add.cpu().double() if with_add else 0)
+    outs = []
+    for wide in (0, 1):
+        old = o.gemm_wide_epilogue(wide)
+        try:
+            out = torch.full((B * 4 * H * W, Cout), float("nan"), device=gpu_device)
+            o.gemm(rows, M, N, Cin, [wp], out, biases=[b.cuda()], addend=add, act=act, slope=0.1, **kw)
+        finally:
+            o.gemm_wide_epilogue(old)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[1].cpu().double(), ref) < KTOL
+
+
 @pytest.mark.parametrize("B,HW,C", [(2, 35, 32), (3, 16, 96), (2, 64, 128), (1, 9, 512), (2, 4, 1024)])
 def test_channelnorm_film(ops, gpu_device, B, HW, C):
     x = rnd(B * HW, C) * 3 + 0.5
