@@ -289,6 +289,64 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float *__restrict__
     }
 }
 
+// Same gradient with a thread per OUTPUT channel (C0 <= 256, Cin <= 16: every net of the reference): dy rows are read coalesced, the
+// chunk's x pixels sit in LDS as [row][CP] (CP = Cin padded to 4 / 8 / 16, read back as 16-byte broadcasts), CP accumulators per
+// thread.  ONE workgroup of 1024 threads per CU: same-address float atomics retire at ~0.2 us each on this chip (measured: 247 us
+// with 1 k blocks, 429 us with 2 k), so the block count IS the run time once the loads are coalesced; the kernel above spends
+// 715 us at the cfg-5 shape (a 64-bit division per multiply, 2 M atomics).
+constexpr int kRowsNT = 1024;
+template <int CP>
+__global__ __launch_bounds__(kRowsNT) void stem_bwd_rows_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dw,
+                                                                long long M, int Cin, int HW, int C0, int slab)
+{
+    __shared__ __attribute__((aligned(16))) float xs[kRowsNT * CP];
+    const int t = threadIdx.x;
+    const int nrg = kRowsNT / C0;                               // row groups: threads [rg * C0, (rg + 1) * C0) take rows rg, rg + nrg, ...
+    const int n = t % C0, rg = t / C0;
+    const bool active = rg < nrg;
+    const long long m0 = (long long)blockIdx.x * slab;
+    const long long m1 = m0 + slab < M ? m0 + slab : M;
+    float acc[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+    for (long long c0 = m0; c0 < m1; c0 += kRowsNT) {
+        __syncthreads();
+        const long long m = c0 + t;
+        if (m < m1) {
+            const long long b = m / HW;
+            const long long pix = m - b * HW;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) xs[t * CP + c] = c < Cin ? x[(b * Cin + c) * HW + pix] : 0.f;
+        }
+        __syncthreads();
+        const int rows = (int)(m1 - c0 < kRowsNT ? m1 - c0 : kRowsNT);
+        if (active) {
+            const float *dyp = dy + c0 * C0 + n;
+#pragma unroll 8
+            for (int r = rg; r < rows; r += nrg) {
+                const float d = dyp[(long long)r * C0];
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) {
+                    const f32x4 v = *(const f32x4 *)(xs + r * CP + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * q + e] = fmaf(d, v[e], acc[4 * q + e]);
+                }
+            }
+        }
+    }
+    // sum the row groups through LDS (reusing xs), then one atomic per weight and block
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CP; ++c) xs[t * CP + c] = active ? acc[c] : 0.f;
+    __syncthreads();
+    for (int i = t; i < C0 * Cin; i += kRowsNT) {
+        const int nn = i / Cin, c = i - nn * Cin;
+        float sum = 0.f;
+        for (int g = 0; g < nrg; ++g) sum += xs[(g * C0 + nn) * CP + c];
+        atomicAdd(dw + i, sum);
+    }
+}
+
 // head: out[b, co, p] = sum_c x[m, c] w[c, co] + bias[co]
 //   dx[m, c] = sum_co dout[b, co, p] w[c, co];  dw[c, co] += sum_m x[m, c] dout[b, co, p];  db[co] += sum dout
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dout,
@@ -333,6 +391,83 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
         for (int pl = 0; pl < 64; ++pl) s += gt[pl * 17 + t];
         atomicAdd(db + t, s);
     }
+}
+
+// The same three gradients with a thread per INPUT channel c (C0 <= 256, Cin <= 16): one pass over the rows reads x[m][c] and writes
+// dx[m][c] coalesced, the tile's dout values come from LDS as 16-byte broadcasts, w[c][:] and the dw[c][:] partial sums stay in
+// registers across the 256-row tiles a block walks.  One workgroup of 1024 threads per CU and one atomic per weight and block (see
+// stem_bwd_rows_kernel: same-address atomics are what the kernel above -- 8 k blocks -- spends its 640 us on at the cfg-5 shape).
+// dx is bit-identical to the kernel above (same fmaf order over co).
+template <int CP>
+__global__ __launch_bounds__(kRowsNT) void head_bwd_rows_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dout,
+                                                                float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db, long long M,
+                                                                int C0, int HW, int Cin, long long ntiles)
+{
+    constexpr int TR = 256;                                             // rows per tile
+    __shared__ __attribute__((aligned(16))) float sm[kRowsNT * CP];     // dout tile [TR][CP]; at the end the row groups' partial sums
+    const int t = threadIdx.x;
+    const int nrg = kRowsNT / C0;
+    const int c = t % C0, rg = t / C0;
+    const bool active = rg < nrg;
+    float wreg[CP], acc[CP], accb = 0.f;
+#pragma unroll
+    for (int co = 0; co < CP; ++co) {
+        wreg[co] = (active && co < Cin) ? w[c * Cin + co] : 0.f;
+        acc[co] = 0.f;
+    }
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long m0 = tile * TR;
+        __syncthreads();
+        for (int i = t; i < TR * CP; i += kRowsNT) {
+            const int co = i / TR, pl = i - co * TR;
+            const long long m = m0 + pl;
+            float v = 0.f;
+            if (m < M && co < Cin) {
+                const long long b = m / HW;
+                v = dout[(b * Cin + co) * HW + (m - b * HW)];
+            }
+            sm[pl * CP + co] = v;
+        }
+        __syncthreads();
+        const int rows = (int)(M - m0 < TR ? M - m0 : TR);
+        if (active) {
+#pragma unroll 8
+            for (int pl = rg; pl < rows; pl += nrg) {
+                const long long m = m0 + pl;
+                const float xv = x[m * C0 + c];
+                float g[CP];
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) {
+                    const f32x4 v = *(const f32x4 *)(sm + pl * CP + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[4 * q + e] = v[e];
+                }
+                float s_ = 0.f;
+#pragma unroll
+                for (int co = 0; co < CP; ++co) {
+                    if (co < Cin) s_ = fmaf(g[co], wreg[co], s_);
+                    acc[co] = fmaf(xv, g[co], acc[co]);
+                }
+                dx[m * C0 + c] = s_;
+            }
+        }
+        if (t < Cin) {
+            float s_ = 0.f;
+            for (int pl = 0; pl < rows; ++pl) s_ += sm[pl * CP + t];
+            accb += s_;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int co = 0; co < CP; ++co) sm[t * CP + co] = active ? acc[co] : 0.f;
+    __syncthreads();
+    for (int i = t; i < C0 * Cin; i += kRowsNT) {
+        const int cc = i / Cin, co = i - cc * Cin;
+        float sum = 0.f;
+        for (int g2 = 0; g2 < nrg; ++g2) sum += sm[(g2 * C0 + cc) * CP + co];
+        atomicAdd(dw + i, sum);
+    }
+    if (t < Cin) atomicAdd(db + t, accb);
 }
 
 // ---- L1 loss (ddpm.py:47 with nn.L1Loss) ----------------------------------------------------------
@@ -737,8 +872,18 @@ extern "C" int ldm_stem_bwd_f32(const float *x, const float *dy, float *dw, int 
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dw, 0, (size_t)C0 * Cin * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_stem_bwd_f32: memset failed"); return LDM_ELAUNCH; }
     const long long M = (long long)B * HW;
-    const int slab = 256;
-    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for(M, slab)), dim3(256), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+    if (C0 <= 256 && Cin <= 16) {
+        long long per = ((M + 255) / 256 + kRowsNT - 1) / kRowsNT * kRowsNT;     // rows per block: ~256 blocks, whole 1024-row chunks
+        if (per > 0x40000000LL) per = 0x40000000LL;
+        const int slab = (int)per;
+        const dim3 grid(blocks_for(M, slab));
+        if (Cin <= 4) hipLaunchKernelGGL(stem_bwd_rows_kernel<4>, grid, dim3(kRowsNT), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+        else if (Cin <= 8) hipLaunchKernelGGL(stem_bwd_rows_kernel<8>, grid, dim3(kRowsNT), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+        else hipLaunchKernelGGL(stem_bwd_rows_kernel<16>, grid, dim3(kRowsNT), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+    } else {
+        const int slab = 256;
+        hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for(M, slab)), dim3(256), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+    }
     LDM_CHECK_LAUNCH("ldm_stem_bwd_f32");
     return LDM_OK;
 }
@@ -754,7 +899,15 @@ extern "C" int ldm_head_bwd_f32(const float *x, const float *w, const float *dou
         return LDM_ELAUNCH;
     }
     const long long M = (long long)B * HW;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(M, 64)), dim3(256), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin);
+    if (C0 <= 256) {
+        const long long ntiles = (M + 255) / 256;
+        const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
+        if (Cin <= 4) hipLaunchKernelGGL(head_bwd_rows_kernel<4>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin, ntiles);
+        else if (Cin <= 8) hipLaunchKernelGGL(head_bwd_rows_kernel<8>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin, ntiles);
+        else hipLaunchKernelGGL(head_bwd_rows_kernel<16>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin, ntiles);
+    } else {
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(M, 64)), dim3(256), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin);
+    }
     LDM_CHECK_LAUNCH("ldm_head_bwd_f32");
     return LDM_OK;
 }

@@ -134,6 +134,40 @@ def test_backward_kernels_against_autograd(gpu_device):
     assert abs(float(loss) - float((p - q).abs().mean())) < 1e-6
 
 
+@pytest.mark.parametrize("B,Cin,HW,C0", [(2, 8, 35, 128), (3, 3, 100, 32), (1, 8, 4096, 96), (2, 12, 300, 64), (64, 8, 4096, 128), (2, 8, 64, 320)])
+def test_stem_weight_gradient_kernel(gpu_device, B, Cin, HW, C0):
+    """dw[n, ci] = sum_m dy[m, n] x[b, ci, p] (the gradient of the 1x1 stem from NCHW, unet.py:77): the thread-per-output-channel
+    kernel (C0 <= 256) and the generic one (C0 = 320) against fp64."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + C0)
+    x = torch.randn(B, Cin, HW, generator=g)
+    dy = torch.randn(B * HW, C0, generator=g)
+    dw = torch.full((C0, Cin), float("nan"), device=gpu_device)
+    ops.stem_bwd(x.cuda(), dy.cuda(), dw, B, Cin, HW, C0)
+    ref = torch.einsum("bpn,bcp->nc", dy.double().reshape(B, HW, C0), x.double())
+    assert rel_l2(dw.cpu().double(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,C0,HW,Cin", [(2, 128, 1000, 8), (1, 32, 70, 3), (4, 64, 40000, 8), (2, 512, 64, 8), (1, 96, 33, 16)])
+def test_head_backward_kernel(gpu_device, B, C0, HW, Cin):
+    """out[b, co, p] = sum_c x[m, c] w[c, co] + bias (unet.py:78 as a rows -> NCHW kernel): dx, dw, db against fp64; 2 500 tiles on
+    2 048 blocks (grid-stride accumulation) and a 4 096-weight head (the per-tile atomics tail) included."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(B * 11 + C0)
+    M = B * HW
+    x = torch.randn(M, C0, generator=g)
+    w = torch.randn(C0, Cin, generator=g) * C0 ** -0.5
+    dout = torch.randn(B, Cin, HW, generator=g)
+    dx = torch.full((M, C0), float("nan"), device=gpu_device)
+    dw = torch.full((C0, Cin), float("nan"), device=gpu_device)
+    db = torch.full((Cin,), float("nan"), device=gpu_device)
+    ops.head_bwd(x.cuda(), w.cuda(), dout.cuda(), dx, dw, db, B, C0, HW, Cin)
+    drows = dout.double().permute(0, 2, 1).reshape(M, Cin)
+    assert rel_l2(dx.cpu().double(), drows @ w.double().t()) < 1e-5
+    assert rel_l2(dw.cpu().double(), x.double().t() @ drows) < 1e-5
+    assert rel_l2(db.cpu().double(), drows.sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("shift,hw", [(0, 8), (3, 8), (3, 16), (0, 4)])
 def test_window_attention_backward(gpu_device, shift, hw):
     """Gradients of the attention block (in-proj, windows incl. padded tokens and the float-mask quirk, out-proj)
