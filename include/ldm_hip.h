@@ -273,6 +273,9 @@ int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *out_planes, i
 /* backward of ldm_window_attention_f32: dqkv [B,H,W,3C]; gradients of zero-padded tokens' k, v go to dbias_pad [3C] */
 int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
                                  float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream);
+/* kernel behind ldm_window_attention_bwd_f32: 1 (default) v_mfma_f32_16x16x4_f32 products, 0 the scalar kernel (A/B tests).
+ * Returns the old value; any other argument only queries. */
+int ldm_window_attention_bwd_mfma(int v);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 training step (BASELINE.json configs[4]: "train_ldm.py ... bf16 ... fwd+bwd HIP kernels"; the reference

@@ -127,6 +127,7 @@ SIGNATURES = {
     "ldm_l1_loss_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P]),
     "ldm_im2col3x3_t_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_window_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_window_attention_bwd_mfma": (_I, [_I]),
     # bf16 training step
     "ldm_gemm_bf16": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
     "ldm_gemm_bf16_gate_fwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P]),

@@ -763,6 +763,295 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
     }
 }
 
+// ---- MFMA version (v_mfma_f32_16x16x4_f32, exact fp32; every window of the reference: L <= 48) ----------------------------------
+// One wave per (sample, window, head) as above, but the five products run on the matrix pipe (the scalar kernel is VALU-bound:
+// 1.6 ms at the cfg-5 stage-0 shape against an HBM floor of 0.4 ms).  Operand conventions of the forward kernel
+// (attention.hip): a lane (c = lane & 15, g = lane >> 4) holds row 16 t + c of a token tile, dims [8 g, 8 g + 8); the C/D map gives
+// a lane ONE column (c) and rows {4 g + e}.  A C/D-layout matrix can be the B operand of the next product directly (contraction
+// index = its rows 16 t + 4 g + e); it cannot be the A operand.  Hence BOTH orientations of the score matrix are computed from the
+// same fragments (operands swapped) instead of transposing through LDS:
+//   S^T = K Qs^T, dP^T = V dO^T  ->  softmax down the columns  ->  dS^T  ->  dQ^T = K^T dS^T   (K^T from an LDS image of K)
+//   S   = Qs K^T, dP   = dO V^T  ->  softmax along the rows     ->  P, dS ->  dK^T = Qs^T dS, dV^T = dO^T P   (Qs, dO images)
+// Results leave as 16-byte stores (token c, dims [16 dt + 4 g, + 4)).  Padded tokens' dk / dv go to the bias gradient (one shuffle
+// tree + 8 atomics per lane group and matrix).
+// DPP lane permutation inside rows of 16 lanes: 0xB1 / 0x4E quad_perm [1,0,3,2] / [2,3,0,1], 0x141 row_half_mirror, 0x140 row_mirror
+template <int CTRL>
+__device__ __forceinline__ float attn_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int NT>
+__global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const AttnB p)
+{
+    constexpr int RS = 36, LT = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int L = p.L, C = p.C;
+    const int IMG = p.L * RS;                      // images hold the L real rows; reads past them are clamped (their partner is an exact 0)
+    float *Ks = smem + wave * (3 * IMG + LT);
+    float *Ql = Ks + IMG, *Gl = Ql + IMG, *Kb = Gl + IMG;
+    const long long gw = (long long)blockIdx.x * 2 + wave;
+    const bool active = gw < p.total_waves;
+    const int head = (int)(gw % p.heads);
+    const long long t1 = gw / p.heads;
+    const int nwin = p.global ? 1 : p.nwh * p.nww;
+    const int win = (int)(t1 % nwin);
+    const long long b = t1 / nwin;
+    const int wr = win / p.nww, wc = win - wr * p.nww;
+    const long long img = b * p.H * p.W;
+    const float scale = 0.17677669529663687f;
+
+    f32x4 kf[NT][2], qf[NT][2], vf[NT][2], gf[NT][2];
+    long long trow[NT];
+    bool tok[NT], tpad[NT];                       // real token / zero-padded token (inside L, outside the image)
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + c;
+            int sy = 0, sx = 0, py = 0, px = 0;
+            const bool ok = j < L && tok_src(p, wr, wc, j, sy, sx, py, px);
+            tok[t] = ok;
+            tpad[t] = j < L && !ok;
+            trow[t] = img + (long long)sy * p.W + sx;
+            const float *row = ok ? p.qkv + trow[t] * 3 * C + head * 32 : p.bias + head * 32;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 z{0.f, 0.f, 0.f, 0.f};
+                const f32x4 qv = *(const f32x4 *)(row + 8 * g + 4 * u);
+                kf[t][u] = *(const f32x4 *)(row + C + 8 * g + 4 * u);
+                vf[t][u] = *(const f32x4 *)(row + 2 * C + 8 * g + 4 * u);
+                gf[t][u] = ok ? *(const f32x4 *)(p.dctx + trow[t] * C + head * 32 + 8 * g + 4 * u) : z;   // cropped outputs: dO = 0
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[t][u][e] = qv[e] * scale;
+                if (j < L) {
+                    *(f32x4 *)(Ks + j * RS + 8 * g + 4 * u) = kf[t][u];
+                    *(f32x4 *)(Ql + j * RS + 8 * g + 4 * u) = qf[t][u];
+                    *(f32x4 *)(Gl + j * RS + 8 * g + 4 * u) = gf[t][u];
+                }
+            }
+        }
+        if (lane < LT) {
+            float kb = -INFINITY;
+            if (lane < L) {
+                int sy, sx, py, px;
+                const bool ok = tok_src(p, wr, wc, lane, sy, sx, py, px);
+                kb = 0.f;
+                if (!p.global) {
+                    if (p.shift == 0) {
+                        kb = ok ? 0.f : -INFINITY;
+                    } else {
+                        int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
+                        my += my < 0 ? p.Hp : 0;
+                        mx += mx < 0 ? p.Wp : 0;
+                        kb = (my < p.H && mx < p.W) ? p.xf[(img + (long long)my * p.W + mx) * C] : 0.f;
+                    }
+                }
+            }
+            Kb[lane] = kb;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    auto zero9 = [](f32x4 (&m)[NT][NT]) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int bq = 0; bq < NT; ++bq) m[a][bq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // ---- column orientation: S^T[k][q], dP^T[k][q]  ->  dS^T  ->  dQ ------------------------------------------------
+    {
+        f32x4 st[NT][NT], dpt[NT][NT];
+        zero9(st);
+        zero9(dpt);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s8 >> 2][s8 & 3], qf[qt][s8 >> 2][s8 & 3], st[kt][qt], 0, 0, 0);
+                    dpt[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][s8 >> 2][s8 & 3], gf[qt][s8 >> 2][s8 & 3], dpt[kt][qt], 0, 0, 0);
+                }
+        float kbv[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kbv[kt][e] = Kb[16 * kt + 4 * g + e];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][qt][e] += kbv[kt][e];
+                    mx = fmaxf(mx, st[kt][qt][e]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][qt][e] = __expf(st[kt][qt][e] - mx);
+                    sum += st[kt][qt][e];
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float dot = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][qt][e] *= inv;
+                    dot = fmaf(st[kt][qt][e], dpt[kt][qt][e], dot);
+                }
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[kt][qt][e] *= dpt[kt][qt][e] - dot;             // dS^T
+        }
+        f32x4 dq[NT][2];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) dq[qt][0] = dq[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const float a = Ks[min(16 * kt + 4 * g + e, L - 1) * RS + 16 * dt + c];      // keys >= L: dS^T is exactly 0
+#pragma unroll
+                    for (int qt = 0; qt < NT; ++qt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, st[kt][qt][e], dq[qt][dt], 0, 0, 0);
+                }
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+            if (tok[qt]) {
+                float *dst = p.dqkv + trow[qt] * 3 * C + head * 32 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    *(f32x4 *)(dst + 16 * dt) = f32x4{dq[qt][dt][0] * scale, dq[qt][dt][1] * scale, dq[qt][dt][2] * scale, dq[qt][dt][3] * scale};
+            }
+    }
+    // ---- row orientation: S[q][k], dP[q][k]  ->  P, dS  ->  dK, dV -----------------------------------------------------
+    f32x4 sm[NT][NT], dpm[NT][NT];
+    zero9(sm);
+    zero9(dpm);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[qt][s8 >> 2][s8 & 3], kf[kt][s8 >> 2][s8 & 3], sm[qt][kt], 0, 0, 0);
+                dpm[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[qt][s8 >> 2][s8 & 3], vf[kt][s8 >> 2][s8 & 3], dpm[qt][kt], 0, 0, 0);
+            }
+    float kbc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) kbc[kt] = Kb[16 * kt + c];
+    // reductions over the 16 lanes of a DPP row (= the 16 key columns of a tile): quad swaps, then half-row and row mirrors --
+    // every lane pairs with a lane holding the complementary partial result, so all 16 end with the same value; no LDS traffic
+    auto row_max = [](float v) {
+        v = fmaxf(v, attn_dpp<0xB1>(v));
+        v = fmaxf(v, attn_dpp<0x4E>(v));
+        v = fmaxf(v, attn_dpp<0x141>(v));
+        return fmaxf(v, attn_dpp<0x140>(v));
+    };
+    auto row_sum = [](float v) {
+        v += attn_dpp<0xB1>(v);
+        v += attn_dpp<0x4E>(v);
+        v += attn_dpp<0x141>(v);
+        return v + attn_dpp<0x140>(v);
+    };
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                  // row q = 16 qt + 4 g + e, this lane's columns k = 16 kt + c
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt][e] += kbc[kt];
+                mx = fmaxf(mx, sm[qt][kt][e]);
+            }
+            mx = row_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt][e] = __expf(sm[qt][kt][e] - mx);
+                sum += sm[qt][kt][e];
+            }
+            const float rsum = row_sum(sum);
+            const float inv = (16 * qt + 4 * g + e < L) ? 1.0f / rsum : 0.f;                // rows past L: P = 0 (their dO image row is clamped)
+            float dot = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt][e] *= inv;                                   // P
+                dot = fmaf(sm[qt][kt][e], dpm[qt][kt][e], dot);
+            }
+            dot = row_sum(dot);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) dpm[qt][kt][e] = sm[qt][kt][e] * (dpm[qt][kt][e] - dot);     // dS
+        }
+    f32x4 dk[NT][2], dv[NT][2];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) dk[kt][0] = dk[kt][1] = dv[kt][0] = dv[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int qrow = min(16 * qt + 4 * g + e, L - 1);          // queries >= L: dS and P are exactly 0
+                const float aq = Ql[qrow * RS + 16 * dt + c];
+                const float ag = Gl[qrow * RS + 16 * dt + c];
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, dpm[qt][kt][e], dk[kt][dt], 0, 0, 0);
+                    dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, sm[qt][kt][e], dv[kt][dt], 0, 0, 0);
+                }
+            }
+    bool padded = false;
+    f32x4 pk[2], pv[2];
+    pk[0] = pk[1] = pv[0] = pv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (tok[kt]) {
+            float *dst = p.dqkv + trow[kt] * 3 * C + head * 32 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                *(f32x4 *)(dst + C + 16 * dt) = dk[kt][dt];
+                *(f32x4 *)(dst + 2 * C + 16 * dt) = dv[kt][dt];
+            }
+        } else if (tpad[kt]) {                    // k, v of a zero-padded token are the in-proj bias: their gradients belong to it
+            padded = true;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                pk[dt] += dk[kt][dt];
+                pv[dt] += dv[kt][dt];
+            }
+        }
+    }
+    if (__any(padded)) {                           // wave-uniform
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sk = row_sum(pk[dt][e]), sv = row_sum(pv[dt][e]);
+                if (c == 0) {
+                    atomicAdd(p.dbias_pad + C + head * 32 + 16 * dt + 4 * g + e, sk);
+                    atomicAdd(p.dbias_pad + 2 * C + head * 32 + 16 * dt + 4 * g + e, sv);
+                }
+            }
+    }
+}
+
 }  // namespace
 
 #define EW4_ENTRY(name, kern, ...)                                                                        \
@@ -942,6 +1231,14 @@ extern "C" int ldm_im2col3x3_t_f32(const float *x, float *out, int B, int H, int
     return LDM_OK;
 }
 
+static int g_attn_bwd_mfma = 1;                       // 0: the scalar kernel (A/B tests)
+extern "C" int ldm_window_attention_bwd_mfma(int v)
+{
+    const int old = g_attn_bwd_mfma;
+    if (v == 0 || v == 1) g_attn_bwd_mfma = v;
+    return old;
+}
+
 extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
                                             float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream)
 {
@@ -962,9 +1259,18 @@ extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_pr
     p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dbias_pad, 0, (size_t)3 * C * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_window_attention_bwd_f32: memset failed"); return LDM_ELAUNCH; }
-    constexpr int LMAX = 36;
-    const size_t smem = 2ull * (2 * LMAX * 36 + 2 * LMAX * (LMAX + 1) + LMAX + 4) * sizeof(float);
-    hipLaunchKernelGGL(window_attention_bwd_kernel<LMAX>, dim3((unsigned)((p.total_waves + 1) / 2)), dim3(128), smem, st, p);
+    const dim3 grid((unsigned)((p.total_waves + 1) / 2));
+    if (g_attn_bwd_mfma) {                              // every window the reference builds has L <= 36
+        const int nt = (p.L + 15) / 16;
+        const size_t smem = 2ull * (3 * p.L * 36 + 16 * nt) * sizeof(float);
+        if (nt == 1) hipLaunchKernelGGL(window_attention_bwd_mfma_kernel<1>, grid, dim3(128), smem, st, p);
+        else if (nt == 2) hipLaunchKernelGGL(window_attention_bwd_mfma_kernel<2>, grid, dim3(128), smem, st, p);
+        else hipLaunchKernelGGL(window_attention_bwd_mfma_kernel<3>, grid, dim3(128), smem, st, p);
+    } else {
+        constexpr int LMAX = 36;
+        const size_t smem = 2ull * (2 * LMAX * 36 + 2 * LMAX * (LMAX + 1) + LMAX + 4) * sizeof(float);
+        hipLaunchKernelGGL(window_attention_bwd_kernel<LMAX>, grid, dim3(128), smem, st, p);
+    }
     LDM_CHECK_LAUNCH("ldm_window_attention_bwd_f32");
     return LDM_OK;
 }

@@ -208,6 +208,11 @@ def gemm_ring(v):
     return _lib.load().ldm_gemm_ring(v)
 
 
+def window_attention_bwd_mfma(v):
+    """Kernel behind window_attention_bwd: 1 (default) MFMA products, 0 the scalar kernel.  Returns the old value."""
+    return _lib.load().ldm_window_attention_bwd_mfma(v)
+
+
 def gemm_variant(v):
     """0 = tile-per-block schedule, 1 = persistent LDS-DMA stream; returns the previous value."""
     return _lib.load().ldm_gemm_variant(v)

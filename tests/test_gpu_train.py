@@ -168,7 +168,36 @@ def test_head_backward_kernel(gpu_device, B, C0, HW, Cin):
     assert rel_l2(db.cpu().double(), drows.sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("shift,hw", [(0, 8), (3, 8), (3, 16), (0, 4)])
+@pytest.mark.parametrize("B,H,W,C,shift", [(2, 8, 8, 64, 0), (2, 8, 8, 64, 3), (1, 20, 14, 128, 3), (3, 16, 16, 32, 0), (2, 4, 4, 64, 0),
+                                            (2, 5, 5, 32, 0), (2, 3, 2, 32, 0), (1, 6, 6, 96, 0), (1, 12, 12, 64, 3)])
+def test_window_attention_backward_mfma_kernel_matches_scalar_kernel(gpu_device, B, H, W, C, shift):
+    """The MFMA backward (16x16x4 fp32 products, both orientations of the score matrix) against the scalar kernel on the same
+    inputs: windows with zero-padded tokens, the float-mask quirk (shift 3), global attention at 16 / 25 / 6 / 36 tokens."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(H * 31 + W + shift)
+    m = B * H * W
+    qkv = (torch.randn(m, 3 * C, generator=g) * 1.5).cuda()
+    bias = torch.randn(3 * C, generator=g).cuda()
+    xf = torch.randn(m, C, generator=g).cuda()
+    dctx = torch.randn(m, C, generator=g).cuda()
+    outs = []
+    for mode in (0, 1):
+        old = ops.window_attention_bwd_mfma(mode)
+        try:
+            dqkv = torch.full((m, 3 * C), float("nan"), device=gpu_device)
+            dpad = torch.full((3 * C,), float("nan"), device=gpu_device)
+            ops.window_attention_bwd(qkv, bias, xf, dctx, dqkv, dpad, B, H, W, C, 6, shift)
+        finally:
+            ops.window_attention_bwd_mfma(old)
+        outs.append((dqkv, dpad))
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    for part in range(3):
+        a, b_ = outs[0][0][:, part * C:(part + 1) * C], outs[1][0][:, part * C:(part + 1) * C]
+        assert rel_l2(b_.cpu().double(), a.cpu().double()) < 1e-5, part
+    assert float((outs[1][1] - outs[0][1]).abs().max()) <= 1e-5 * max(1.0, float(outs[0][1].abs().max()))
+
+
+@pytest.mark.parametrize("shift,hw", [(0, 8), (3, 8), (3, 16), (0, 4), (0, 5), (3, 10)])
 def test_window_attention_backward(gpu_device, shift, hw):
     """Gradients of the attention block (in-proj, windows incl. padded tokens and the float-mask quirk, out-proj)
     against autograd through the oracle.  The float "mask" is detached in the reference (attention.py:76-81 runs

@@ -41,5 +41,8 @@ for s in range(4):
     for shift in (0, 3):
         tf = timeit(lambda: ops.window_attention(qkv, bias, xf, out, B, R, R, C, 6, shift))
         tb = timeit(lambda: ops.window_attention_bwd(qkv, bias, xf, dctx, dqkv, dbp, B, R, R, C, 6, shift))
-        print("C %4d R %2d shift %d: fwd %.3f ms (%.0f GB/s), bwd %.3f ms (%.0f GB/s)"
-              % (C, R, shift, tf, M * C * 16 / tf / 1e6, tb, M * C * 32 / tb / 1e6), flush=True)
+        old = ops.window_attention_bwd_mfma(0)
+        ts = timeit(lambda: ops.window_attention_bwd(qkv, bias, xf, dctx, dqkv, dbp, B, R, R, C, 6, shift))
+        ops.window_attention_bwd_mfma(old)
+        print("C %4d R %2d shift %d: fwd %.3f ms (%.0f GB/s), bwd %.3f ms (%.0f GB/s; scalar kernel %.3f ms)"
+              % (C, R, shift, tf, M * C * 16 / tf / 1e6, tb, M * C * 32 / tb / 1e6, ts), flush=True)
