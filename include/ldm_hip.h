@@ -243,6 +243,9 @@ int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulat
 /* out[Cc, R] = x[R, Cc]^T and csum[c] = sum_r x[r][c] in one pass (activation transpose + bias gradient) */
 int ldm_transpose_colsum_f32(const float *x, float *out, float *csum, long long R, int Cc, void *stream);
 int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream);        /* split-K sum */
+/* two such sums with the same S in one launch (a weight gradient's partial planes and its bias gradient's); n_a, n_b multiples of 4;
+ * each result equals ldm_reduce_partials_f32's bit for bit */
+int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n_a, const float *parts_b, float *out_b, long long n_b, int S, void *stream);
 /* Weight gradient of a 1x1 conv / Linear WITHOUT transposed copies (autograd of modules.py:10-12, unet.py:20-21,
  * attention in/out projections): out[s][n][k] = sum over rows m of split s of a[m*lda + n] * b[m*ldb + k], i.e.
  * dW = dY^T X with the pixel rows as the contraction.  N, K multiples of 128; M / splits a multiple of 32; the caller

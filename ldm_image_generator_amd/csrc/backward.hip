@@ -94,11 +94,11 @@ __global__ void reduce_partials_kernel(const float *__restrict__ parts, float *_
 // in plane order.  Fixed association ((q0 + q1) + q2) + q3, no atomics: the result does not depend on scheduling.  The scalar
 // kernel above had one dependent 4-byte load chain per element: 15 us per launch on average over the ~330 weight-gradient
 // reductions of a training step (S = 4 ... 128 planes of 50 k ... 3 M elements), most of it latency.
-__global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const f32x4 *__restrict__ parts, f32x4 *__restrict__ out, int S, long long n4)
+__device__ __forceinline__ void reduce_partials_v4_body(const f32x4 *__restrict__ parts, f32x4 *__restrict__ out, int S, long long n4, long long block)
 {
     __shared__ f32x4 part[3][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + lane;
+    const long long i = block * 64 + lane;
     const bool live = i < n4;
     const int s0 = (int)((long long)S * q / 4), s1 = (int)((long long)S * (q + 1) / 4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -126,6 +126,19 @@ __global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const f32x4 *__
         acc += part[2][lane];
         out[i] = acc;
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const f32x4 *__restrict__ parts, f32x4 *__restrict__ out, int S, long long n4)
+{
+    reduce_partials_v4_body(parts, out, S, n4, blockIdx.x);
+}
+
+// two sums with the same S in one launch (a weight gradient's planes and its bias gradient's): blocks [0, blocks_a) take job a
+__global__ __launch_bounds__(256) void reduce_partials_pair_kernel(const f32x4 *__restrict__ pa, f32x4 *__restrict__ oa, long long na4, unsigned blocks_a,
+                                                                   const f32x4 *__restrict__ pb, f32x4 *__restrict__ ob, long long nb4, int S)
+{
+    if (blockIdx.x < blocks_a) reduce_partials_v4_body(pa, oa, S, na4, blockIdx.x);
+    else reduce_partials_v4_body(pb, ob, S, nb4, blockIdx.x - blocks_a);
 }
 
 // ---- ChannelNorm + FiLM backward ----------------------------------------------------------------
@@ -1118,6 +1131,19 @@ extern "C" int ldm_reduce_partials_f32(const float *parts, float *out, int S, lo
     else
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, parts, out, S, n);
     LDM_CHECK_LAUNCH("ldm_reduce_partials_f32");
+    return LDM_OK;
+}
+
+extern "C" int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n_a, const float *parts_b, float *out_b, long long n_b,
+                                           int S, void *stream)
+{
+    LDM_REQUIRE(parts_a && out_a && parts_b && out_b && S > 0 && n_a > 0 && n_b > 0, "ldm_reduce_partials_pair_f32: bad arguments");
+    LDM_REQUIRE(n_a % 4 == 0 && n_b % 4 == 0, "ldm_reduce_partials_pair_f32: element counts must be multiples of 4");
+    LDM_REQUIRE(ldm_aligned16(parts_a) && ldm_aligned16(out_a) && ldm_aligned16(parts_b) && ldm_aligned16(out_b), "ldm_reduce_partials_pair_f32: unaligned pointer");
+    const unsigned ba = blocks_for(n_a / 4, 64), bb = blocks_for(n_b / 4, 64);
+    hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3(ba + bb), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)parts_a, (f32x4 *)out_a, n_a / 4, ba,
+                       (const f32x4 *)parts_b, (f32x4 *)out_b, n_b / 4, S);
+    LDM_CHECK_LAUNCH("ldm_reduce_partials_pair_f32");
     return LDM_OK;
 }
 

@@ -15,7 +15,7 @@ from ._lib import (A_CONV3X3, A_ROWS, ACT_GATE, ACT_LRELU, ACT_NONE, ACT_RELU, O
 
 __all__ = ["gemm", "pointer_table", "channelnorm_film", "film", "sincos_embed", "window_attention", "avgpool2", "stem_nchw", "head_nchw",
            "ddim_update", "qsample", "rgb_head", "nchw_to_nhwc", "nhwc_to_nchw", "to_uint8_hwc", "prof_enable", "prof_read", "prof_read_class", "prof_read_bytes", "gate_fwd", "gate_bwd", "relu_bwd", "add_", "colsum", "transpose_colsum", "reduce_partials", "channelnorm_film_bwd",
-           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "window_attention_bwd_mfma", "gemm_variant", "gemm_wide_epilogue", "gemm_ring", "lrelu_bwd", "im2col3x3", "space_to_depth2", "rgb_head_bwd", "gemm_tn", "gconv3x3_wgrad",
+           "avgpool2_bwd", "sumpool2", "stem_bwd", "head_bwd", "l1_loss", "l1_loss_bwd", "im2col3x3_t", "window_attention_bwd", "window_attention_bwd_mfma", "reduce_partials_pair", "gemm_variant", "gemm_wide_epilogue", "gemm_ring", "lrelu_bwd", "im2col3x3", "space_to_depth2", "rgb_head_bwd", "gemm_tn", "gconv3x3_wgrad",
            "ACT_NONE", "ACT_RELU", "ACT_GATE", "ACT_LRELU", "A_ROWS", "A_CONV3X3", "O_ROWS", "O_CONVT2X2", "O_UP2",
            "SEG_N", "SEG_K"]
 
@@ -295,6 +295,16 @@ def gconv3x3_wgrad(x, dy, planes, B, H, W, C, splits):
 def reduce_partials(parts, S, n, out):
     _call("ldm_reduce_partials_f32", _dev(parts, "parts"), _dev(out, "out"), S, n)
     return out
+
+
+def reduce_partials_pair(parts_a, n_a, out_a, parts_b, n_b, out_b, S):
+    """reduce_partials twice (same S) in one launch; falls back to two launches when a count is not a multiple of 4."""
+    if n_a % 4 or n_b % 4:
+        reduce_partials(parts_a, S, n_a, out_a)
+        reduce_partials(parts_b, S, n_b, out_b)
+    else:
+        _call("ldm_reduce_partials_pair_f32", _dev(parts_a, "parts_a"), _dev(out_a, "out_a"), n_a, _dev(parts_b, "parts_b"), _dev(out_b, "out_b"), n_b, S)
+    return out_a, out_b
 
 
 def channelnorm_film_bwd(x, film, slot, dxf, dres, dx, dfilm, B, HW, C, eps=1e-4, unique_slots=False):

@@ -144,9 +144,13 @@ def grad_weight_rows(dy, x, m_red):
     else:
         parts = torch.empty(s, n_out, k_out, device=dev, dtype=torch.float32)
         ops.gemm_tn(dy.x, x.x, parts, m_red, n_out, k_out, s, colsum=cs)
+        if want_cs:                                             # both sums in one launch
+            dy._cs = torch.empty(n_out, device=dev, dtype=torch.float32)
+            ops.reduce_partials_pair(parts, n_out * k_out, out, cs, n_out, dy._cs, s)
+            return out
         ops.reduce_partials(parts, s, n_out * k_out, out)
     if want_cs:
-        dy._cs = cs[0] if s == 1 else ops.reduce_partials(cs, s, n_out, torch.empty(n_out, device=dev, dtype=torch.float32))
+        dy._cs = cs[0]
     return out
 
 
@@ -485,10 +489,12 @@ def grad_weight_rows16(dy16, x16, m_red, want_colsum=True):
         return out, (cs[0] if want_colsum else None)
     parts = torch.empty(s, n_out, k_out, device=dev, dtype=torch.float32)
     ops.gemm_tn_bf16(dy16, x16, parts, m_red, n_out, k_out, s, colsum=cs)
+    if want_colsum:                                             # both sums in one launch
+        csum = torch.empty(n_out, device=dev, dtype=torch.float32)
+        ops.reduce_partials_pair(parts, n_out * k_out, out, cs, n_out, csum, s)
+        return out, csum
     ops.reduce_partials(parts, s, n_out * k_out, out)
-    if want_colsum:
-        cs = ops.reduce_partials(cs, s, n_out, torch.empty(n_out, device=dev, dtype=torch.float32))
-    return out, cs
+    return out, None
 
 
 def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):

@@ -61,6 +61,20 @@ def test_reduce_partials_fixed_order_sum(gpu_device, S, n):
     assert float((out.double() - ref).abs().max()) <= 4e-7 * float(parts.abs().double().sum(0).max())
 
 
+@pytest.mark.parametrize("S,na,nb", [(1, 64, 8), (2, 4096, 128), (16, 128 * 384, 384), (128, 1000 * 4, 12), (7, 256, 260)])
+def test_reduce_partials_pair_equals_two_single_launches(gpu_device, S, na, nb):
+    """ldm_reduce_partials_pair_f32 (a weight gradient's planes and its bias gradient's in one launch) == two single launches, bit for bit."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(S + na)
+    pa, pb = torch.randn(S, na, generator=g).cuda(), torch.randn(S, nb, generator=g).cuda()
+    oa, ob = torch.full((na,), float("nan"), device=gpu_device), torch.full((nb,), float("nan"), device=gpu_device)
+    ops.reduce_partials_pair(pa, na, oa, pb, nb, ob, S)
+    ra, rb = torch.empty(na, device=gpu_device), torch.empty(nb, device=gpu_device)
+    ops.reduce_partials(pa, S, na, ra)
+    ops.reduce_partials(pb, S, nb, rb)
+    assert torch.equal(oa, ra) and torch.equal(ob, rb)
+
+
 @pytest.mark.parametrize("B,H,W,C,S", [(2, 8, 8, 64, 1), (4, 16, 16, 128, 2), (32, 4, 4, 256, 4), (1, 6, 64, 32, 1), (3, 32, 32, 64, 8)])
 def test_grouped_conv_weight_gradient_kernel(gpu_device, B, H, W, C, S):
     """dW of the 32-per-group 3x3 conv from the row-major activations (no transposed im2col) vs autograd."""
