@@ -504,6 +504,9 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
         if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, true, 0, false, true>(p, groups, st);
     }
     if (p.M <= 32 && unit % 128 == 0) return launch_stream_w<1, 4, 1, 1, false, LDM_A_ROWS>(p, groups, st);
+    // 33..64 rows against many weight matrices (the FiLM MLPs of the 8 x 8 level: 64 rows x 18 blocks x 8 M weights): a
+    // weight-streaming launch; 64 x 128 tiles waste no rows and keep 16-KB weight slices per K-step
+    if (p.M <= 64 && unit % 128 == 0) return launch_stream<2, 2, 1, 2, false, LDM_A_ROWS, 0, false>(p, groups, st);      // direct epilogue: the tile has too few LDS slices for the wide one
     // 128x128 tiles where N allows and the tile count still fills the chip (two workgroups per CU): a third fewer LDS-DMA instructions per MFMA (with the wide
     // epilogue the instance fits two workgroups per CU without spills); measured +5-6 % at C = 256 / 512, neutral elsewhere
     if (unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512) return launch_stream_w<2, 2, 2, 2, false, LDM_A_ROWS>(p, groups, st);
