@@ -116,6 +116,9 @@ __global__ void relu_bwd_bf16_kernel(const u32x4 *__restrict__ dy, const u32x4 *
 }
 
 // ---- ChannelNorm + FiLM, forward: fp32 in, fp32 and/or bf16 out ----------------------------------------------------------------
+// NV float4 per lane and R row groups per wave (see channelnorm_film_rows_kernel in elementwise.hip: the loads of all R rows are in
+// flight before the first reduction; arithmetic and its order do not depend on NV / R)
+template <int NV, int R>
 __global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *__restrict__ x, const float *__restrict__ film, const int *__restrict__ slot,
                                                                   float *__restrict__ out32, unsigned short *__restrict__ out16, long long rows, int HW,
                                                                   int C, float eps, int lpr)
@@ -123,44 +126,53 @@ __global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *_
     const int lane = threadIdx.x & 63;
     const int rpw = 64 / lpr;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long row = wave * rpw + lane / lpr;
     const int sub = lane % lpr;
     const int c4n = C >> 2;
-    const bool live = row < rows;
-    const f32x4 *xr = (const f32x4 *)(x + (live ? row : 0) * C);
-    f32x4 v[kMaxV];
-    float s = 0.f;
+    f32x4 v[R][NV];
+    long long row[R];
+    bool live[R];
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i) {
-        const int c4 = sub + i * lpr;
-        v[i] = (live && c4 < c4n) ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    for (int r = 0; r < R; ++r) {
+        row[r] = (wave * R + r) * rpw + lane / lpr;
+        live[r] = row[r] < rows;
+        const f32x4 *xr = (const f32x4 *)(x + (live[r] ? row[r] : 0) * C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = sub + i * lpr;
+            v[r][i] = (live[r] && c4 < c4n) ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    const float mean = group_sum(s, lpr) / (float)C;
-    float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxV; ++i)
-        if (sub + i * lpr < c4n)
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                ss += d * d;
+        for (int i = 0; i < NV; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        const float mean = group_sum(s, lpr) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (sub + i * lpr < c4n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[r][i][e] - mean;
+                    ss += d * d;
+                }
+        const float den = sqrtf(group_sum(ss, lpr) / (float)(C - 1) + eps);     // unbiased, modules.py:24
+        if (!live[r]) continue;
+        const int b = (int)(row[r] / HW), pix = (int)(row[r] - (long long)b * HW);
+        const int sl = slot ? slot[b] : 0;
+        const f32x4 *fr = (const f32x4 *)(film + ((long long)sl * HW + pix) * 2 * C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = sub + i * lpr;
+            if (c4 < c4n) {
+                const f32x4 mu = fr[c4], bi = fr[c4n + c4];
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn((v[r][i][e] - mean) / den, mu[e]), bi[e]);
+                if (out32) ((f32x4 *)(out32 + row[r] * C))[c4] = o;
+                if (out16) ((u32x2 *)(out16 + row[r] * C))[c4] = pack4(o);
             }
-    const float den = sqrtf(group_sum(ss, lpr) / (float)(C - 1) + eps);     // unbiased, modules.py:24
-    if (!live) return;
-    const int b = (int)(row / HW), pix = (int)(row - (long long)b * HW);
-    const int sl = slot ? slot[b] : 0;
-    const f32x4 *fr = (const f32x4 *)(film + ((long long)sl * HW + pix) * 2 * C);
-#pragma unroll
-    for (int i = 0; i < kMaxV; ++i) {
-        const int c4 = sub + i * lpr;
-        if (c4 < c4n) {
-            const f32x4 mu = fr[c4], bi = fr[c4n + c4];
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn((v[i][e] - mean) / den, mu[e]), bi[e]);
-            if (out32) ((f32x4 *)(out32 + row * C))[c4] = o;
-            if (out16) ((u32x2 *)(out16 + row * C))[c4] = pack4(o);
         }
     }
 }
@@ -309,8 +321,19 @@ extern "C" int ldm_channelnorm_film_bf16(const float *x, const float *film, cons
     const int lpr = pow2_lanes(C / 4);
     const long long rows = (long long)B * HW;
     const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
-    hipLaunchKernelGGL(channelnorm_film_mp_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, out_f32,
-                       (unsigned short *)out_bf16, rows, HW, C, eps, lpr);
+    const int nv = (C / 4 + lpr - 1) / lpr;
+    const int r = (nv <= 2 && waves >= 4 * 16384) ? 4 : 1;                 // as launch_channelnorm_film (elementwise.hip)
+    const dim3 grid(blocks_for((waves + r - 1) / r, 4));
+#define LDM_CNF16_LAUNCH(NV_, R_)                                                                                                      \
+    hipLaunchKernelGGL((channelnorm_film_mp_kernel<NV_, R_>), grid, dim3(256), 0, (hipStream_t)stream, x, film, slot, out_f32,        \
+                       (unsigned short *)out_bf16, rows, HW, C, eps, lpr)
+    if (nv == 1 && r == 4) LDM_CNF16_LAUNCH(1, 4);
+    else if (nv == 2 && r == 4) LDM_CNF16_LAUNCH(2, 4);
+    else if (nv == 1) LDM_CNF16_LAUNCH(1, 1);
+    else if (nv == 2) LDM_CNF16_LAUNCH(2, 1);
+    else if (nv <= 4) LDM_CNF16_LAUNCH(4, 1);
+    else LDM_CNF16_LAUNCH(kMaxV, 1);
+#undef LDM_CNF16_LAUNCH
     LDM_CHECK_LAUNCH("ldm_channelnorm_film_bf16");
     return LDM_OK;
 }
