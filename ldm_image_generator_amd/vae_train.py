@@ -307,8 +307,13 @@ class DiscriminatorFunction(torch.autograd.Function):
         x = fake.contiguous().float() if real is None else torch.cat([fake.float(), real.float()], 0).contiguous()
         b, cin, h, w = x.shape
         c0 = disc.input_layer.weight.shape[0]
-        rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
-        ops.stem_nchw(x, w2d(disc.input_layer), disc.input_layer.bias.detach(), rows, b, cin, h * w, c0)
+        p0 = _pad32(c0)                                                       # the stem writes the padded width directly
+        w_in = torch.zeros(p0, cin, device=dev, dtype=torch.float32)
+        w_in[:c0] = w2d(disc.input_layer)
+        b_in = torch.zeros(p0, device=dev, dtype=torch.float32)
+        b_in[:c0] = disc.input_layer.bias.detach()
+        rows = torch.empty(b * h * w, p0, device=dev, dtype=torch.float32)
+        ops.stem_nchw(x, w_in, b_in, rows, b, cin, h * w, p0)
         logit = torch.zeros(1, device=dev, dtype=torch.float32)
         feat = torch.zeros(1, device=dev, dtype=torch.float32)
         tape = []
@@ -340,7 +345,7 @@ class DiscriminatorFunction(torch.autograd.Function):
                 ops.gemm(s2d, b * h * w, pco, 4 * pci, [packed], rows, biases=[pd.bias])
                 rec["down"] = dict(pd=pd, packed=packed, s2d=s2d)
             tape.append(rec)
-        fctx.disc, fctx.tape, fctx.x, fctx.params, fctx.nf, fctx.has_real = disc, tape, x, params, nf, real is not None
+        fctx.disc, fctx.tape, fctx.x, fctx.params, fctx.nf, fctx.has_real, fctx.w_in = disc, tape, x, params, nf, real is not None, w_in
         return logit.reshape(()), feat.reshape(())
 
     @staticmethod
@@ -391,12 +396,13 @@ class DiscriminatorFunction(torch.autograd.Function):
                 pblk.c2.unpad(pg, grads)
         b, cin, h0, w0 = x.shape
         c0 = disc.input_layer.weight.shape[0]
-        dw0 = torch.empty(c0, cin, device=dev, dtype=torch.float32)
-        ops.stem_bwd(x, drows, dw0, b, cin, h0 * w0, c0)
-        grads[disc.input_layer.weight] = dw0.reshape(disc.input_layer.weight.shape)
-        grads[disc.input_layer.bias] = ops.colsum(drows, drows.shape[0], c0)
+        p0 = drows.shape[1]
+        dw0 = torch.empty(p0, cin, device=dev, dtype=torch.float32)
+        ops.stem_bwd(x, drows, dw0, b, cin, h0 * w0, p0)
+        grads[disc.input_layer.weight] = dw0[:c0].reshape(disc.input_layer.weight.shape).contiguous()
+        grads[disc.input_layer.bias] = ops.colsum(drows, drows.shape[0], p0)[:c0].contiguous()
         dfake = None
         if fctx.needs_input_grad[1]:                                          # real_x.requires_grad = False (vae.py:150)
             dfake = torch.empty(nf, cin, h0, w0, device=dev, dtype=torch.float32)
-            ops.head_nchw(drows[:nf * h0 * w0], w2d(disc.input_layer).contiguous(), None, dfake, nf, c0, h0 * w0, cin)
+            ops.head_nchw(drows[:nf * h0 * w0], fctx.w_in, None, dfake, nf, p0, h0 * w0, cin)
         return (None, dfake, None) + tuple(grads.get(p) for p in fctx.params)
