@@ -229,6 +229,12 @@ size_t ldm_unet_workspace_bytes(const ldm_unet_plan *plan, int B, int H, int W, 
 int ldm_unet_forward_f32(const ldm_unet_plan *plan, const float *x_nchw, const long long *t_unique, int nT, const int *slot,
                          const int *decisions /* host */, int B, int H, int W, void *workspace, size_t ws_bytes,
                          float *out_nchw, void *stream);
+/* the same forward; films_ready != 0 skips the FiLM tables because an earlier call on THIS workspace with the same plan, B, H, W and
+ * (t_unique, nT) left them there (DDPM.sample computes the tables of all its timesteps in the first denoise step: they depend on t,
+ * never on x; each step then passes slot[b] = its step index).  The caller owns that guarantee. */
+int ldm_unet_forward_ex_f32(const ldm_unet_plan *plan, const float *x, const long long *t_unique, int nT, const int *slot,
+                            const int *decisions, int B, int H, int W, void *workspace, size_t workspace_bytes, float *out,
+                            int films_ready, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step (ddpm.py:39-48 + autograd of unet.py / modules.py / attention.py).  GEMM-shaped

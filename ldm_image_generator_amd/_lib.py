@@ -92,6 +92,8 @@ SIGNATURES = {
     "ldm_unet_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(UNetPlanDesc), _I, _I, _I, _I]),
     "ldm_unet_forward_f32": (_I, [ctypes.POINTER(UNetPlanDesc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I, _P,
                                   ctypes.c_size_t, _P, _P]),
+    "ldm_unet_forward_ex_f32": (_I, [ctypes.POINTER(UNetPlanDesc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I, _P,
+                                     ctypes.c_size_t, _P, _I, _P]),
     "ldm_prof_enable": (_I, [_I]),
     "ldm_prof_read": (_I, [ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ldm_prof_read_bytes": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),

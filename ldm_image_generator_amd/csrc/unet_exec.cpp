@@ -173,8 +173,22 @@ extern "C" size_t ldm_unet_workspace_bytes(const ldm_unet_plan *pl, int B, int H
     return b.off;
 }
 
+extern "C" int ldm_unet_forward_ex_f32(const ldm_unet_plan *pl, const float *x, const long long *t_unique, int nT, const int *slot,
+                                       const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, int films_ready,
+                                       void *st);
+
 extern "C" int ldm_unet_forward_f32(const ldm_unet_plan *pl, const float *x, const long long *t_unique, int nT, const int *slot,
                                     const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, void *st)
+{
+    return ldm_unet_forward_ex_f32(pl, x, t_unique, nT, slot, decisions, B, H, W, workspace, ws_bytes, out, 0, st);
+}
+
+// films_ready != 0: the FiLM tables of (t_unique, nT) are already in this workspace from an earlier call with the same plan, shapes and
+// timesteps (the denoise loop computes them for ALL its timesteps in the first step -- they depend on t, never on x -- and every step
+// then selects its rows through `slot`); the caller owns that guarantee.
+extern "C" int ldm_unet_forward_ex_f32(const ldm_unet_plan *pl, const float *x, const long long *t_unique, int nT, const int *slot,
+                                       const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, int films_ready,
+                                       void *st)
 {
     LDM_REQUIRE(pl && x && t_unique && decisions && workspace && out, "ldm_unet_forward_f32: null pointer");
     LDM_REQUIRE(B > 0 && nT > 0, "ldm_unet_forward_f32: bad batch");
@@ -191,7 +205,7 @@ extern "C" int ldm_unet_forward_f32(const ldm_unet_plan *pl, const float *x, con
     LDM_REQUIRE(total == pl->nblocks, "ldm_unet_forward_f32: plan has %d blocks, stages sum to %d", pl->nblocks, total);
 
     // ---- FiLM tables of every block: sin/cos codes per level, then two grouped GEMMs per level (unet.py:18-21)
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n && !films_ready; ++i) {
         const int C = lv[i].C, G = lv[i].nblk;
         LDM_REQUIRE(G <= LDM_MAX_TABLE, "ldm_unet_forward_f32: %d blocks at level %d exceed the pointer-table size", G, i);
         RUN(ldm_sincos_embed_f32(t_unique, nT, lv[i].H, lv[i].W, C, pl->pos_freq[i], pl->time_freq[i], L.codes[i], st));

@@ -79,13 +79,15 @@ class DDPM(nn.Module):
         alpha = torch.cumprod((1 - self.beta), dim=0)
         bar = tqdm(total=len(steps), disable=not progress)
         hint_ok = hasattr(self.model, "_uniform_time")
+        if hasattr(self.model, "_films_key"):
+            self.model._films_key = None
         t_dev = torch.tensor([int(s) for s in steps], dtype=torch.int64, device=device)   # one upload for the whole loop
         try:
             for i, (t, t_next) in enumerate(zip(reversed(steps), reversed(steps_next))):
                 t_tensor = torch.full((x_shape[0],), t, device=device)
                 if hint_ok:                                      # every sample shares t: FiLM computed once
                     k = len(steps) - 1 - i
-                    self.model._uniform_time = (t, t_dev[k:k + 1])
+                    self.model._uniform_time = (t, t_dev[k:k + 1], t_dev, k)  # (value, its device tensor, the whole schedule, index)
                 e_theta = self.model(x=x, time=t_tensor, condition=None)
                 e = torch.randn(*x_shape, device=device)
                 if shard is not None and eta != 0:
@@ -105,5 +107,7 @@ class DDPM(nn.Module):
         finally:
             if hint_ok:
                 self.model._uniform_time = None
+                if hasattr(self.model, "_films_key"):
+                    self.model._films_key = None              # the tables in the workspace belong to this loop only
             bar.close()
         return x

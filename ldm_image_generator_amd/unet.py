@@ -217,6 +217,9 @@ class UNet(nn.Module):
         self._plan = None                  # (key, ctypes plan, keep-alive list) for the native executor
         self._workspace = None
         self.native_forward = True         # inference forwards run through ldm_unet_forward_f32 (one C call per forward)
+        self.hoist_films = True            # denoise loops compute the FiLM tables of all their timesteps in the first step
+        self._films_key = None             # identity of the tables currently in the workspace (None: not valid)
+        self._slot_table = None
 
     def _level_blocks(self, i):
         n = len(self.encoder_stages)
@@ -353,18 +356,34 @@ class UNet(nn.Module):
             d = blk.draw()
             dec[k] = -1 if d is None else d[0] * 4 + d[1]
         lib = _lib.load()
-        nt = ctx.t_unique.numel()
+        # denoise loop (DDPM.sample hands over its whole timestep list): the FiLM tables depend on t, never on x, so the first step
+        # computes them for ALL timesteps in one pair of GEMM launches per level (the weights -- 0.74 GB -- are read once per loop
+        # instead of once per step) and every step selects its rows through slot[b] = step index
+        sched = self._uniform_time if (self.hoist_films and isinstance(self._uniform_time, tuple) and len(self._uniform_time) == 4) else None
+        if sched is not None:
+            t_unique, step = sched[2], int(sched[3])
+            nt = t_unique.numel()
+            if self._slot_table is None or self._slot_table.shape != (nt, b) or self._slot_table.device != dev:
+                self._slot_table = torch.arange(nt, dtype=torch.int32, device=dev).repeat_interleave(b).reshape(nt, b).contiguous()
+            slot = self._slot_table[step]
+        else:
+            t_unique, nt, slot = ctx.t_unique, ctx.t_unique.numel(), ctx.slot
+            self._films_key = None
         need = lib.ldm_unet_workspace_bytes(ctypes.byref(plan), b, h, w, nt)
         if need == 0:
             raise ValueError("UNet: input %dx%d is not divisible by 2**%d" % (h, w, len(self.channels) - 1))
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._films_key = None
+        key = None if sched is None else (t_unique.data_ptr(), nt, b, h, w, self._workspace.data_ptr(), id(plan), self._plan[0])
+        ready = int(key is not None and key == self._films_key)
         out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
         x = x.contiguous().float()
-        _lib.check(lib.ldm_unet_forward_f32(ctypes.byref(plan), x.data_ptr(), ctx.t_unique.data_ptr(), nt,
-                                            None if ctx.slot is None else ctx.slot.data_ptr(), dec, b, h, w,
-                                            self._workspace.data_ptr(), need, out.data_ptr(),
-                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_unet_forward_f32")
+        _lib.check(lib.ldm_unet_forward_ex_f32(ctypes.byref(plan), x.data_ptr(), t_unique.data_ptr(), nt,
+                                               None if slot is None else slot.data_ptr(), dec, b, h, w,
+                                               self._workspace.data_ptr(), need, out.data_ptr(), ready,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_unet_forward_ex_f32")
+        self._films_key = key
         return out
 
     def forward(self, x, time, condition=None):

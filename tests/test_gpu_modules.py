@@ -425,3 +425,29 @@ def test_native_forward_is_bit_identical_to_python_orchestration(tiny_unet, full
         tiny_unet.native_forward = True
         assert torch.equal(outs[0], outs[1])
         blk.conv.weight.div_(1.5)
+
+
+def test_sample_with_hoisted_film_tables_is_bit_identical(gpu_device):
+    """DDPM.sample computes the FiLM tables of ALL its timesteps in the first denoise step (one pair of GEMM launches per level for the
+    whole loop) and selects rows by step index afterwards: same bits as computing them step by step, in eval and in train mode
+    (stochastic depth live), and a second loop with another schedule of the same length does not see stale tables."""
+    import random
+    from ldm_image_generator_amd import synth
+    from ldm_image_generator_amd.ddpm import DDPM
+    from ldm_image_generator_amd.unet import UNet
+    net = UNet(stages=[1, 2, 1], channels=[32, 64, 128])
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()))
+    d = DDPM(model=net.cuda())
+    for mode in ("eval", "train"):
+        getattr(d, mode)()
+        outs = []
+        for hoist in (True, False):
+            net.hoist_films = hoist
+            outs.append(d.sample(x_shape=(3, 8, 16, 16), seed=5, num_steps=7, progress=False))
+        assert torch.equal(outs[0], outs[1]), mode
+        net.hoist_films = True
+        a = d.sample(x_shape=(3, 8, 16, 16), seed=5, num_steps=7, schedule=[0, 100, 250, 400, 600, 800, 999], progress=False)
+        net.hoist_films = False
+        b = d.sample(x_shape=(3, 8, 16, 16), seed=5, num_steps=7, schedule=[0, 100, 250, 400, 600, 800, 999], progress=False)
+        net.hoist_films = True
+        assert torch.equal(a, b) and not torch.equal(a, outs[0]), mode
