@@ -218,6 +218,7 @@ class UNet(nn.Module):
         self._workspace = None
         self.native_forward = True         # inference forwards run through ldm_unet_forward_f32 (one C call per forward)
         self.hoist_films = True            # denoise loops compute the FiLM tables of all their timesteps in the first step
+        self.hoist_budget_bytes = 16 << 30 # ... unless those tables would need more workspace than this (2.3 GB at 50 steps, 32x32 latents)
         self._films_key = None             # identity of the tables currently in the workspace (None: not valid)
         self._slot_table = None
 
@@ -360,6 +361,11 @@ class UNet(nn.Module):
         # computes them for ALL timesteps in one pair of GEMM launches per level (the weights -- 0.74 GB -- are read once per loop
         # instead of once per step) and every step selects its rows through slot[b] = step index
         sched = self._uniform_time if (self.hoist_films and isinstance(self._uniform_time, tuple) and len(self._uniform_time) == 4) else None
+        if sched is not None:                                    # tables of the whole loop: (codes 2C + hidden 4C x blocks + rows 2C x blocks) floats
+            n_t = sched[2].numel()
+            need_f = sum(n_t * (h >> i) * (w >> i) * c * (2 + 6 * len(self._level_blocks(i))) for i, c in enumerate(self.channels))
+            if 4 * need_f > self.hoist_budget_bytes:             # very long schedules / large latents: stay with the per-step form
+                sched = None
         if sched is not None:
             t_unique, step = sched[2], int(sched[3])
             nt = t_unique.numel()

@@ -451,3 +451,6 @@ def test_sample_with_hoisted_film_tables_is_bit_identical(gpu_device):
         b = d.sample(x_shape=(3, 8, 16, 16), seed=5, num_steps=7, schedule=[0, 100, 250, 400, 600, 800, 999], progress=False)
         net.hoist_films = True
         assert torch.equal(a, b) and not torch.equal(a, outs[0]), mode
+    net.hoist_budget_bytes = 1024                                 # tables larger than the budget: per-step form, same bits
+    c = d.sample(x_shape=(3, 8, 16, 16), seed=5, num_steps=7, schedule=[0, 100, 250, 400, 600, 800, 999], progress=False)
+    assert torch.equal(c, a) and net._slot_table is not None
