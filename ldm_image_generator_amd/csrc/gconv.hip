@@ -236,6 +236,10 @@ struct GcTile {
     float *obase;
 };
 
+// WIDE: addend and output travel as 16-byte row pieces (4 + 4 VMEM instructions per tile and wave instead of 16 + 16 dwords): the
+// finished values cross from the MFMA C/D map to rows through a private 32 x 36-float LDS slice per wave.  Same arithmetic.
+constexpr int GC_SROW = 36;
+template <bool WIDE>
 __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, int ntm, int total, int chunk, float inv_w, float inv_h)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -247,6 +251,8 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
     const int NPp = (NP + 7) & ~7;
     const int npieces = NPp / 8;
     float *Zs = lds, *Ab = lds + 32, *Ws = Ab + 2 * NPp * 32;
+    float *Sw = Ws + 9 * 32 * 32 + wave * (32 * GC_SROW);       // WIDE: this wave's transpose slice
+    const int rsub = lane >> 3, cc = lane & 7;                 // WIDE: row inside an 8-row group, 16-byte chunk of the 32 columns
     const int first = (int)blockIdx.x * chunk;
     const int last = first + chunk < total ? first + chunk : total;
     if (first >= last) return;
@@ -295,8 +301,15 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
         const int col = n_g * (int)p.o_gstride + r;
         const long long row_first = n_m0 + wave * 32 + 4 * h;
         T.bias = *(p.bias[0] ? p.bias[0] + n_g * p.b_gstride + r : ldm_zero_block);
-        T.obase = p.out + row_first * p.ldo + col;
-        n_abase = p.addend ? p.addend + row_first * p.ldadd + col : ldm_zero_block;
+        if (WIDE) {
+            const long long rw = n_m0 + wave * 32 + rsub;
+            const int cw = n_g * (int)p.o_gstride + 4 * cc;
+            T.obase = p.out + rw * p.ldo + cw;
+            n_abase = p.addend ? p.addend + rw * p.ldadd + cw : ldm_zero_block;
+        } else {
+            T.obase = p.out + row_first * p.ldo + col;
+            n_abase = p.addend ? p.addend + row_first * p.ldadd + col : ldm_zero_block;
+        }
         n_lda = p.addend ? (int)p.ldadd : 0;
     };
     auto next_tap = [&](int tap, GcTile &T) {
@@ -307,6 +320,11 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
         T.asw[tap] = ok ? (slot >> 1) & 7 : 0;
     };
     auto next_pre = [&](int e, GcTile &T) { T.pre[e] = n_abase[((e & 3) + 8 * (e >> 2)) * n_lda]; };
+    auto next_pre4 = [&](int k, GcTile &T) {                  // WIDE: rows 8 k + rsub, four columns
+        const f32x4 v = *(const f32x4 *)(n_abase + 8 * k * n_lda);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T.pre[4 * k + c] = v[c];
+    };
 
     if (t < 8) *(f32x4 *)(Zs + t * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     int cur_g = first / ntm;
@@ -318,8 +336,13 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
     next_coords2(C);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) next_tap(tap, C);
+    if (WIDE) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) next_pre(e, C);
+        for (int k = 0; k < 4; ++k) next_pre4(k, C);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) next_pre(e, C);
+    }
     N = C;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -371,8 +394,14 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
             if (q == 1) next_coords1((id - first + 1) & 1);
             if (q == 2) next_coords2(N);
             if (q >= 3 && q <= 11) next_tap(q - 3, N);
-            if (q >= 12 && q <= 27) next_pre(q - 12, N);
-            if (q >= 20 && pending) obase_prev[(((q - 20) & 3) + 8 * ((q - 20) >> 2)) * ldo_e] = outv[q - 20];
+            if (WIDE) {
+                if (q >= 12 && q <= 15) next_pre4(q - 12, N);
+                if (q >= 20 && q <= 23 && pending)
+                    *(f32x4 *)(obase_prev + 8 * (q - 20) * ldo_e) = f32x4{outv[4 * (q - 20)], outv[4 * (q - 20) + 1], outv[4 * (q - 20) + 2], outv[4 * (q - 20) + 3]};
+            } else {
+                if (q >= 12 && q <= 27) next_pre(q - 12, N);
+                if (q >= 20 && pending) obase_prev[(((q - 20) & 3) + 8 * ((q - 20) >> 2)) * ldo_e] = outv[q - 20];
+            }
         };
         f32x4 a0, a1, b0, b1;
         frag(0, a0, b0);
@@ -397,20 +426,40 @@ __global__ __launch_bounds__(NW * 64) void gconv3x3_pipe_kernel(const GemmP p, i
         __syncthreads();
 
         // finalise this tile's values (stored under the next tile's MFMAs, or by the flush below)
+        if (WIDE) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float v = acc[e] + C.bias;
-            const float vr = fmaxf(v, 0.f), vl = v > 0.f ? v : v * slope;
-            v = relu ? vr : vl;
-            if (has_add) v += C.pre[e];
-            outv[e] = v;
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[e] + C.bias;
+                const float vr = fmaxf(v, 0.f), vl = v > 0.f ? v : v * slope;
+                Sw[((e & 3) + 8 * (e >> 2) + 4 * h) * GC_SROW + r] = relu ? vr : vl;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 o = *(const f32x4 *)(Sw + (8 * k + rsub) * GC_SROW + 4 * cc);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) outv[4 * k + c] = has_add ? o[c] + C.pre[4 * k + c] : o[c];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[e] + C.bias;
+                const float vr = fmaxf(v, 0.f), vl = v > 0.f ? v : v * slope;
+                v = relu ? vr : vl;
+                if (has_add) v += C.pre[e];
+                outv[e] = v;
+            }
         }
         obase_prev = C.obase;
         pending = true;
         C = N;
     }
+    if (WIDE) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) obase_prev[((e & 3) + 8 * (e >> 2)) * ldo_e] = outv[e];
+        for (int k = 0; k < 4; ++k) *(f32x4 *)(obase_prev + 8 * k * ldo_e) = f32x4{outv[4 * k], outv[4 * k + 1], outv[4 * k + 2], outv[4 * k + 3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) obase_prev[((e & 3) + 8 * (e >> 2)) * ldo_e] = outv[e];
+    }
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------
@@ -508,6 +557,8 @@ __global__ __launch_bounds__(256, 2) void gconv3x3_wgrad_kernel(const float *__r
 
 }  // namespace
 
+int g_gconv_wide = 1;          // 0: dword addend loads / output stores in the pipelined kernel (A/B tests; see ldm_gemm_wide_epilogue)
+
 // Returns 1 if the problem is a 32-in / 32-out-per-group 3x3 convolution this kernel covers (and launches it), else 0.
 int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipStream_t st)
 {
@@ -522,7 +573,8 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
     static int cus = 0;
     if (cus == 0) {
         (void)hipFuncSetAttribute((const void *)gconv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)gconv3x3_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)gconv3x3_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)gconv3x3_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         int dev = 0;
         cus = 256;
         (void)hipGetDevice(&dev);
@@ -531,10 +583,17 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
     const int wgs = (int)(total < cus ? total : cus);
     const int chunk = (int)((total + wgs - 1) / wgs);
     const unsigned grid = (unsigned)((total + chunk - 1) / chunk);
-    if (p.M % BM == 0 && p.M < (1 << 24) && p.ldo * 64ll < 0x7fffffffLL)          // every tile full: the software-pipelined variant
-        hipLaunchKernelGGL(gconv3x3_pipe_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
-                           1.0f / (float)p.H);
-    else
+    if (p.M % BM == 0 && p.M < (1 << 24) && p.ldo * 64ll < 0x7fffffffLL) {        // every tile full: the software-pipelined variant
+        const size_t smem_w = smem + (size_t)NW * 32 * GC_SROW * sizeof(float);
+        const bool wide = g_gconv_wide && smem_w <= 160 * 1024 && ldm_aligned16(p.out) && p.ldo % 4 == 0 && p.o_gstride % 4 == 0 &&
+                          (!p.addend || (ldm_aligned16(p.addend) && p.ldadd % 4 == 0));
+        if (wide)
+            hipLaunchKernelGGL(gconv3x3_pipe_kernel<true>, dim3(grid), dim3(NW * 64), smem_w, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
+                               1.0f / (float)p.H);
+        else
+            hipLaunchKernelGGL(gconv3x3_pipe_kernel<false>, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
+                               1.0f / (float)p.H);
+    } else
         hipLaunchKernelGGL(gconv3x3_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
     return 1;
 }

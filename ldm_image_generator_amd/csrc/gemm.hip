@@ -321,7 +321,12 @@ bool splitk_launch(const ldm_gemm_desc &d, const GemmP &p, bool gate, hipStream_
 
 int ldm_gemm_stream_wide(int v);
 
-extern "C" int ldm_gemm_wide_epilogue(int v) { return ldm_gemm_stream_wide(v); }
+extern int g_gconv_wide;
+extern "C" int ldm_gemm_wide_epilogue(int v)
+{
+    if (v == 0 || v == 1) g_gconv_wide = v;          // the grouped conv's 16-byte row epilogue follows the same switch
+    return ldm_gemm_stream_wide(v);
+}
 
 extern "C" int ldm_gemm_variant(int v)
 {
