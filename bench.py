@@ -300,6 +300,8 @@ def main():
             "outputs_finite": finite,
             "gemm_variant": knobs["gemm_variant"], "wide_epilogue": knobs["wide_epilogue"], "gemm_ring": knobs["gemm_ring"],
             "gemm_variant_note": "1 = exact fp32 (v_mfma_f32_32x32x2_f32), the schedule `value` was measured under; 2 appears only in split_schedule",
+            "film_tables": ("per_loop: every sample() call computes the FiLM tables of all its timesteps in its first denoise step (they depend on t, "
+                            "not on x); bit-identical to per-step" if getattr(net, "hoist_films", False) else "per_step"),
             "roofline": {"bound": "mfma", "kernel": "ldm_gemm_f32 family (gemm_ring_kernel, gemm_stream_kernel, gconv3x3_pipe_kernel; v_mfma_f32_32x32x2_f32), all launches of the timed region",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
