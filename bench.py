@@ -45,17 +45,48 @@ def cpu_baseline(threads):
         random.seed(0)
         O.unet_forward(usd, x[:1], torch.full((1,), 999), training=False)          # warm-up
         t0 = time.perf_counter()
-        for t in (999, 978):
-            O.unet_forward(usd, x, torch.full((4,), t), training=False)
+        eps = [O.unet_forward(usd, x, torch.full((4,), t), training=False) for t in CPU_SAMPLE_STEPS]
         t_step = (time.perf_counter() - t0) / 8.0                                   # s per sample-step
         O.vae_decode(dsd, x[:1])
         t0 = time.perf_counter()
-        O.vae_decode(dsd, x[:2])
+        img = O.vae_decode(dsd, x[:2])
         t_dec = (time.perf_counter() - t0) / 2.0                                    # s per image
-    return dict(value=1.0 / (50 * t_step + t_dec), unit="images/s", cores=threads, kind="port",
+    line = dict(value=1.0 / (50 * t_step + t_dec), unit="images/s", cores=threads, kind="port",
                 sample="oracle/ldm_oracle.py: full-size UNet eval-mode, 2 denoise steps x 4 latents + 2 decodes; "
                        "images/s = 1/(50*t_sample_step + t_decode)",
                 sample_steps_per_sec=1.0 / t_step, decode_images_per_sec=1.0 / t_dec)
+    return line, dict(eps=eps, img=img)
+
+
+CPU_SAMPLE_STEPS = (999, 978)
+
+
+def gpu_probe(net, dec, dev):
+    """The HIP path on exactly the inputs cpu_baseline() times the oracle on (same formula weights, same x, same timesteps): two
+    UNet forwards on 4 latents and the decode of 2 of them.  Taken while the weights are still the formula weights (the
+    training-step leg moves them)."""
+    was_training = net.training
+    net.eval()
+    with torch.no_grad():
+        x = torch.randn(4, 8, 32, 32, generator=torch.Generator().manual_seed(0)).to(dev)
+        eps = []
+        for t in CPU_SAMPLE_STEPS:
+            random.seed(0)
+            eps.append(net(x=x, time=torch.full((4,), t, device=dev), condition=None).cpu())
+        img = dec(x[:2]).cpu()
+    net.train(was_training)
+    return dict(eps=eps, img=img)
+
+
+def gpu_vs_cpu(gpu, cpu):
+    """GPU output compared to the CPU output of this run.  Stated fp32 tolerance: rel-L2 <= 2e-5 each."""
+    errs = {}
+    for t, got, ref in zip(CPU_SAMPLE_STEPS, gpu["eps"], cpu["eps"]):
+        errs["unet_t%d" % t] = float((got.double() - ref.double()).norm() / ref.double().norm())
+    errs["decode"] = float((gpu["img"].double() - cpu["img"].double()).norm() / cpu["img"].double().norm())
+    worst = max(errs.values())
+    return {"rel_l2": errs, "worst": worst, "tolerance": 2e-5, "ok": bool(worst <= 2e-5),
+            "note": "HIP path vs the oracle outputs of cpu_baseline's own timed sample (4 latents x 2 UNet forwards, 2 decodes)"}
 
 
 def traffic_table():
@@ -80,6 +111,8 @@ def main():
                     help="what the single all-gather moves: the fp32 images SURVEY 8(d) defines the metric on (default), or the "
                          "device-side uint8 HWC post-process of sample_ldm.py:75-77 (a quarter of the bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-slices-check", action="store_true", help="skip the N = 1 self-check (4 rows of the timed batch re-run alone)")
+    ap.add_argument("--no-cfg2-leg", action="store_true", help="skip the BASELINE configs[1] leg (pixel-space 64x64, batch 64, UNet only)")
     ap.add_argument("--no-train-mode-leg", action="store_true",
                     help="skip the secondary measurement in the reference-faithful mode (no .eval(): stochastic depth live)")
     ap.add_argument("--no-split-leg", action="store_true",
@@ -149,7 +182,7 @@ def main():
         ops.prof_enable(rank == 0)
         t0 = time.perf_counter()
         for i in range(steps):
-            out = one_pass(100 + i)
+            out = one_pass(100 + args.steps - steps + i)      # every leg ends on seed 100 + K - 1: their last outputs are comparable
         fence()
         dt = time.perf_counter() - t0
         abytes = ops.prof_read_bytes(-1) if rank == 0 else 0.0
@@ -177,17 +210,32 @@ def main():
             shard_check = {"rel_l2": err, "tolerance": tol, "ok": bool(err <= tol), "rows": [lo1, lo1 + 4],
                            "note": "rank 0 alone vs rows gathered from rank 1 (batch 4 vs %d: other GEMM tile paths, fp32 re-association only)" % B}
         fence()
+    slices_check = None
+    if world == 1 and not args.no_slices_check and B >= 8:
+        # N = 1: the same property inside one GPU -- 4 rows of the timed batch re-run alone (same seed -> same expert decisions;
+        # batch 4 takes other GEMM tile / split-K paths than batch B: fp32 re-association only)
+        lo1 = (B // 2) & ~3
+        z = ddpm.sample((4, 8, 32, 32), seed=100 + args.steps - 1, num_steps=T, x_init=x_t[lo1:lo1 + 4], progress=False)
+        alone = decode(z).double()
+        got = out[lo1:lo1 + 4].double()
+        err = float((alone - got).norm() / alone.norm().clamp_min(1e-30))
+        tol = 5e-6 if args.gather == "f32" else 2e-2
+        slices_check = {"rel_l2": err, "tolerance": tol, "ok": bool(err <= tol), "rows": [lo1, lo1 + 4],
+                        "note": "rows of the last timed pass re-run alone as a batch of 4 (what makes batch sharding exact)"}
+        del alone, got, z
 
+    probe = gpu_probe(net, dec, dev) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    sec_steps = max(2, args.steps // 4)            # passes of the secondary sampling legs (they are never `value`)
     # secondary leg: what the reference's scripts actually do -- they never call .eval(), so SwinBlocks are skipped with
     # p = 0.25 during sampling too (unet.py:39); fewer FLOPs per image, hence reported beside, not as, the headline
     train_leg = None
     if not args.no_train_mode_leg and args.mode == "eval":
         net.train(True)
-        dt3, (l3, ms3, fl3, _), out3 = measure(1, args.steps)
+        dt3, (l3, ms3, fl3, _), out3 = measure(1, sec_steps)
         net.train(False)
-        train_leg = {"value": gb * args.steps / dt3, "unit": "images/s", "ms_per_step": dt3 / args.steps * 1e3,
+        train_leg = {"value": gb * sec_steps / dt3, "unit": "images/s", "ms_per_step": dt3 / sec_steps * 1e3, "steps": sec_steps,
                      "gemm_tflops": fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else None,
-                     "executed_gflop_per_sample_step": fl3 / 1e9 / (B * args.steps) / T if rank == 0 else None,
+                     "executed_gflop_per_sample_step": fl3 / 1e9 / (B * sec_steps) / T if rank == 0 else None,
                      "outputs_finite": bool(torch.isfinite(out3.float()).all().item()),
                      "note": "reference-faithful train mode (stochastic depth live while sampling), same seeds"}
         del out3
@@ -199,11 +247,11 @@ def main():
         keep = out[: min(16, out.shape[0])].clone()
         del out
         old = ops.gemm_variant(2)
-        dt2, (l2, ms2, fl2, _), out2 = measure(1, args.steps)
+        dt2, (l2, ms2, fl2, _), out2 = measure(1, sec_steps)
         ops.gemm_variant(old)
         d = (out2[: keep.shape[0]].double() - keep.double())
         eq = fl2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else None
-        split = {"value": gb * args.steps / dt2, "unit": "images/s", "ms_per_step": dt2 / args.steps * 1e3,
+        split = {"value": gb * sec_steps / dt2, "unit": "images/s", "ms_per_step": dt2 / sec_steps * 1e3, "steps": sec_steps,
                  "gemm_tflops_fp32_equivalent": eq,
                  "roofline": None if eq is None else {"bound": "mfma", "achieved": eq, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s",
                                                       "frac": eq / (BF16_MFMA_PEAK_TFLOPS / 6.0),
@@ -214,6 +262,41 @@ def main():
         del out2
     else:
         del out
+
+    # BASELINE.json configs[1]: sample_ddpm.py, pixel space 64x64, 50 steps, batch 64, UNet only (no VAE).  The reference's script
+    # crashes on 3-channel input with the default 8-channel UNet, so the harness uses
+    # UNet(input_channels=3); its 36 SwinBlocks and ch_convs are the SAME modules as the headline net (only stem / head differ).
+    cfg2 = None
+    if not args.no_cfg2_leg and args.mode == "eval":
+        net2 = UNet(input_channels=3, stages=[0, 0, 0, 0])                # cheap shell: stem, head and empty stages ...
+        for i in range(len(net.encoder_stages)):                          # ... filled with the headline net's stages
+            net2.encoder_stages[i] = net.encoder_stages[i]
+            net2.decoder_stages[i] = net.decoder_stages[i]
+        ends = {k: v for k, v in net2.state_dict().items() if k.startswith(("encoder_first", "decoder_last"))}
+        net2.load_state_dict(synth.fill_state_dict(ends), strict=False)
+        net2 = net2.to(dev).eval()
+        d2 = DDPM(model=net2)
+        b2 = 64
+        xp = torch.randn(b2, 3, 64, 64, generator=torch.Generator().manual_seed(0)).to(dev)
+        d2.sample((b2, 3, 64, 64), seed=0, num_steps=T, x_init=xp, progress=False)
+        fence()
+        ops.prof_enable(rank == 0)
+        t0 = time.perf_counter()
+        for i in range(2):
+            o2 = d2.sample((b2, 3, 64, 64), seed=100 + i, num_steps=T, x_init=xp, progress=False)
+        fence()
+        dtc = max_over_ranks(time.perf_counter() - t0)
+        l2c, msc, flc = ops.prof_read() if rank == 0 else (0, 0.0, 0.0)
+        ops.prof_enable(False)
+        famc = flc / (msc * 1e-3) / 1e12 if msc > 0 else None
+        cfg2 = {"value": b2 * world * 2 / dtc, "unit": "images/s", "denoise_steps_per_sec": 2 * T / dtc, "steps": 2, "ms_per_step": dtc / 2 * 1e3,
+                "config": {"workload": "sample_ddpm 64x64 pixel space, %d DDIM steps, batch %d per GPU, UNet(input_channels=3) only, eval-mode" % (T, b2)},
+                "gemm_tflops": famc, "outputs_finite": bool(torch.isfinite(o2).all().item()),
+                "roofline": None if famc is None else {"bound": "mfma", "achieved": famc, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                       "frac": famc / FP32_MFMA_PEAK_TFLOPS, "kernel": "ldm_gemm_f32 family, hipEvents per launch"},
+                "algorithmic_tflops": b2 * 2 * T * 54.98e9 / dtc / 1e12}
+        del net2, d2, o2, xp
+        torch.cuda.empty_cache()
 
     # BASELINE.json configs[4]: one optimisation step of train_ldm.py:76-86 at the per-GPU shape of "global batch 1024 over
     # 8 GPUs, 512x512 -> latents [128, 8, 64, 64]": q-sample, UNet forward with the tape, L1 loss, hand-written backward,
@@ -322,14 +405,19 @@ def main():
             line["dist_world_size"] = dist.get_world_size()
             line["dist_backend"] = dist.get_backend()
             line["sharded_equals_unsharded"] = shard_check
+        if slices_check is not None:
+            line["slices_check"] = slices_check
         if train_leg is not None:
             line["train_mode"] = train_leg
         if split is not None:
             line["split_schedule"] = split
         if train_step is not None:
             line["train_step"] = train_step
+        if cfg2 is not None:
+            line["cfg2"] = cfg2
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64))
+            line["cpu_baseline"], cpu_out = cpu_baseline(min(os.cpu_count() or 1, 64))
+            line["cpu_baseline"]["gpu_vs_cpu_rel_l2"] = gpu_vs_cpu(probe, cpu_out)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -2,19 +2,32 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container and on
 the GPU box alike.  The library is built IN-TREE (next to this file) so that it
-travels with the repo snapshot.
+travels with the repo snapshot.  Every source is compiled to its own object
+(in parallel, re-done only when the source or a header changed) and the objects
+are linked into the one shared library.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")           # git-ignored and gpurun-ignored: only the .so travels
 LIB = os.path.join(HERE, "libldm_hip.so")
-SOURCES = ["gemm.hip", "gemm_stream.hip", "gconv.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "backward.hip", "unet_exec.cpp", "prof.cpp", "gemm_bf16.hip", "gemm_ring.hip", "bf16_ops.hip", "gconv_bf16.hip", "gconv_wgrad_bf16.hip", "vq.hip", "vae_bwd.hip"]
+SOURCES = ["gemm.hip", "gemm_stream.hip", "gconv.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "backward.hip", "unet_exec.cpp", "prof.cpp", "gemm_bf16.hip", "gemm_ring.hip", "bf16_ops.hip", "gconv_bf16.hip", "gconv_wgrad_bf16.hip", "vq.hip", "vae_bwd.hip",
+           "conv3x3_bf16.hip", "infer_bf16.hip", "batched_ops.hip"]
 # -ffp-contract=off: products and sums round separately unless the source says fmaf(); several
 # kernels reproduce the reference's op-by-op fp32 rounding (ddim_update, qsample, FiLM, uint8).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "ldm_hip.h")]
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
 def needs_build():
@@ -25,21 +38,39 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
+
+    def compile_one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            return obj, ""
+        cmd = [hipcc] + FLAGS + ["-c", "-o", obj, path]
+        if verbose:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stdout))
+        return obj, res.stdout
+
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        done = list(pool.map(compile_one, _sources()))
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        for _, log in done:
+            print(log)
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in done],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
-    if verbose:
-        print(res.stdout)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
     return LIB
 
 
 if __name__ == "__main__":
-    build(force=True, verbose="-v" in sys.argv)
+    build(force="-f" in sys.argv, verbose="-v" in sys.argv)
     print("built", LIB)

@@ -350,11 +350,8 @@ extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_b
         hipLaunchKernelGGL(window_attention_mfma_kernel<3>, dim3(blocks), dim3(256), 4ull * (48 * 36 + 48) * sizeof(float), st, p);
     } else {
         const size_t smem = 4ull * (2 * 64 * 32 + 64) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)window_attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr_done = true;
-        }
+        static LdmLdsOptIn opt_in;
+        (void)opt_in((const void *)window_attention_kernel<64>, smem);
         hipLaunchKernelGGL(window_attention_kernel<64>, dim3(blocks), dim3(256), smem, st, p);
     }
     LDM_CHECK_LAUNCH("ldm_window_attention_f32");

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdarg>
+#include <atomic>
 #include "../../include/ldm_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,40 @@ void ldm_prof_end(void *h, hipStream_t st);
             return LDM_ELAUNCH;                                                  \
         }                                                                        \
     } while (0)
+
+// Per-device one-time setup.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only, so a process
+// that drives several GPUs must repeat it per device; the masks are atomics (bit = device ordinal), so concurrent first calls
+// at worst both set the attribute.  One process per GPU (bench.py, torchrun) only ever sets bit `local rank`.
+struct LdmLdsOptIn {
+    std::atomic<unsigned long long> ok{0}, bad{0};
+    // true when the current device accepts `bytes` of dynamic LDS for `kern`
+    bool operator()(const void *kern, size_t bytes)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (ok.load(std::memory_order_acquire) & bit) return true;
+        if (bad.load(std::memory_order_acquire) & bit) return false;
+        const bool good = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+        if (!good) (void)hipGetLastError();
+        (good ? ok : bad).fetch_or(bit, std::memory_order_release);
+        return good;
+    }
+};
+
+// compute units of the current device (cached per device ordinal)
+static inline int ldm_cu_count()
+{
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 
 static inline bool ldm_aligned16(const void *p) { return (((unsigned long long)p) & 15ull) == 0; }
 

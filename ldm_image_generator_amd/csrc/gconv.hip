@@ -570,16 +570,11 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
     if (total > 0x3fffffffLL) return 0;
     const int NPp = (BM + 2 * p.W + 2 + 7) & ~7;
     const size_t smem = ((size_t)32 + 2 * (size_t)NPp * 32 + 9 * 32 * 32) * sizeof(float);
-    static int cus = 0;
-    if (cus == 0) {
-        (void)hipFuncSetAttribute((const void *)gconv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)gconv3x3_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)gconv3x3_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int dev = 0;
-        cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    static LdmLdsOptIn opt_a, opt_b, opt_c;
+    (void)opt_a((const void *)gconv3x3_kernel, 150 * 1024);
+    (void)opt_b((const void *)gconv3x3_pipe_kernel<false>, 150 * 1024);
+    (void)opt_c((const void *)gconv3x3_pipe_kernel<true>, 160 * 1024);
+    const int cus = ldm_cu_count();
     const int wgs = (int)(total < cus ? total : cus);
     const int chunk = (int)((total + wgs - 1) / wgs);
     const unsigned grid = (unsigned)((total + chunk - 1) / chunk);
@@ -608,11 +603,8 @@ extern "C" int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *ou
     LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(dy), "ldm_gconv3x3_wgrad_f32: unaligned pointer");
     const int NPp = (WG_BM + 2 * W + 2 + 7) & ~7;
     const size_t smem = ((size_t)32 + (size_t)NPp * 32 + WG_BM * 32) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)gconv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
+    static LdmLdsOptIn opt_in;
+    (void)opt_in((const void *)gconv3x3_wgrad_kernel, 80 * 1024);
     void *rec = ldm_prof_begin(LDM_PROF_GCONV_WG, 2.0 * (double)M * C * 288.0, (hipStream_t)stream,
                                8.0 * (double)M * C + 4.0 * splits * (double)C * 288.0);
     hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(C / 32, splits), dim3(256), smem, (hipStream_t)stream, x, dy, out_planes, (int)M, H, W, C,

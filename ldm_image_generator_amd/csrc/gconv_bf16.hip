@@ -94,13 +94,7 @@ extern "C" int ldm_gconv3x3_bf16(const void *x, const void *w, const float *bias
     GcP16 p{};
     p.x = (const unsigned short *)x; p.w = (const unsigned short *)w; p.bias = bias; p.addend = addend; p.out = out;
     p.M = (int)M; p.H = H; p.W = W; p.C = C; p.G = C / 32; p.tiles_m = (int)((M + 31) / 32);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    const int cus = ldm_cu_count();
     // waves: a multiple of lcm(4, G) (a wave keeps its group; a workgroup = 4 consecutive groups of the same pixels), ~8 per CU
     const int quantum = p.G % 4 == 0 ? p.G : 4 * p.G;
     const long long items = (long long)p.tiles_m * p.G;

@@ -127,11 +127,8 @@ extern "C" int ldm_gconv3x3_wgrad_bf16(const void *x, const void *dy, float *out
     p.per_split = ((p.Mp + splits - 1) / splits + GT - 1) / GT * GT;
     const size_t smem = ((size_t)GT * 32 + (size_t)(GT + 2 * (p.Wp + 1)) * 32) * sizeof(unsigned short);
     LDM_REQUIRE(smem <= 150 * 1024, "ldm_gconv3x3_wgrad_bf16: W=%d too wide for the LDS halo image", W);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)gconv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_done = true;
-    }
+    static LdmLdsOptIn opt_in;
+    (void)opt_in((const void *)gconv3x3_wgrad_bf16_kernel, 150 * 1024);
     hipStream_t st = (hipStream_t)stream;
     void *rec = ldm_prof_begin(LDM_PROF_GCONV_BF16, 2.0 * (double)B * H * W * C * 288.0, st, 4.0 * (double)B * H * W * C + 4.0 * 4 * splits * C * 288.0);
     hipLaunchKernelGGL(gconv3x3_wgrad_bf16_kernel, dim3(C / 32, splits), dim3(256), smem, st, p);

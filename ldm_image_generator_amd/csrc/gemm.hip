@@ -168,12 +168,9 @@ int launch(const GemmP &p, int groups, hipStream_t st)
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr size_t smem = 2ull * (BM + NB) * 32 * sizeof(float);
-    static bool attr_done = false;
+    static LdmLdsOptIn opt_in;
     auto kern = gemm_f32_kernel<WM, WN, TM, TN, GATE, AMODE>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    (void)opt_in((const void *)kern, smem);
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     dim3 grid(ntm * ntn, groups, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
@@ -405,8 +402,8 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
     const double a_elems = (double)d->M * (d->a_mode == LDM_A_CONV3X3 ? d->Cin : d->K) * (d->a_gstride || groups == 1 ? groups : 1);
     const double o_elems = (double)d->M * d->N * groups * (d->o_mode == LDM_O_UP2 ? 4.0 : 1.0);
     const double algo_bytes = 4.0 * (a_elems + (double)d->N * d->K * groups * (gate ? 2.0 : 1.0) + o_elems * (d->addend ? 2.0 : 1.0));
+    LDM_REQUIRE(!(gate && d->a_mode == LDM_A_CONV3X3), "ldm_gemm_f32: GATE with conv3x3 unsupported");       // before the profiler opens a record
     void *rec = ldm_prof_begin(LDM_PROF_GEMM, 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0), st, algo_bytes);
-    if (gate && d->a_mode == LDM_A_CONV3X3) { ldm_set_error("ldm_gemm_f32: GATE with conv3x3 unsupported"); return LDM_EINVAL; }
     if (!(d->workspace && splitk_launch(*d, p, gate, st))) launch_any(p, groups, gate, d->a_mode, st);
     ldm_prof_end(rec, st);
     LDM_CHECK_LAUNCH("ldm_gemm_f32");

@@ -281,11 +281,8 @@ void tn_launch(const TnP16 &p, long long blocks, hipStream_t st)
 {
     constexpr int NS = KT == 1 ? 4 : 3;
     constexpr size_t smem = (size_t)NS * (1 + KT) * TSUB * sizeof(unsigned short);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)gemm_tn_bf16_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    static LdmLdsOptIn opt_in;
+    (void)opt_in((const void *)gemm_tn_bf16_kernel<KT>, smem);
     hipLaunchKernelGGL(gemm_tn_bf16_kernel<KT>, dim3((unsigned)blocks), dim3(256), smem, st, p);
 }
 

@@ -458,16 +458,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
 template <int ET, int NJ, bool GATE, bool OBF, bool ADD = false, bool GF = false>
 int ring_launch(const GemmP &p, hipStream_t st)
 {
-    static int state = 0, cus = 256;                         // 0 unknown, 1 usable, -1 the device refuses 160 KiB of LDS per workgroup
+    static LdmLdsOptIn opt_in;                               // per device: a device that refuses 160 KiB of LDS per workgroup falls back to the stream kernel
     auto kern = gemm_ring_kernel<ET, NJ, GATE, OBF, ADD, GF>;
-    if (state == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        state = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSMEM) == hipSuccess ? 1 : -1;
-        (void)hipGetLastError();
-    }
-    if (state < 0) return 0;
+    if (!opt_in((const void *)kern, RSMEM)) return 0;
+    const int cus = ldm_cu_count();
     const int ntm = p.M / RT, ntn = p.N / (GATE ? 128 : 128 * NJ);
     const int total = ntm * ntn;
     int grid = total < cus ? total : cus;
@@ -494,12 +488,7 @@ int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32, 
     // ahead of it), a tile is at least 8 steps long, and -- fp32 only -- an in-place addend comes with K >= 384 (its loads are not
     // prefetched under the last K-step as in the stream kernel: out-projections at K = 128 / 256 lost 6 %)
     const bool any = g_ring >= 2;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
+    const int cus = ldm_cu_count();
     auto fills = [&](long long tiles) {
         if (any) return true;
         const long long rounds = (tiles + cus - 1) / cus;

@@ -428,17 +428,16 @@ int launch_stream(const GemmP &p, int groups, hipStream_t st)
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NB = GATE ? 2 * BN : BN;
     constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
-    static int slots = 0;
+    static LdmLdsOptIn opt_in;
+    static std::atomic<int> per_cu_cache{0};
     auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE, ET, OBF, SCAT>;
-    if (slots == 0) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int per_cu = 2;
+    (void)opt_in((const void *)kern, smem);
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
+    if (per_cu == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
-        slots = cus * (per_cu > 4 ? 4 : per_cu);                          // resident workgroups (no grid barrier: a wrong guess only skews load)
+        per_cu_cache.store(per_cu, std::memory_order_relaxed);
     }
+    const int slots = ldm_cu_count() * (per_cu > 4 ? 4 : per_cu);          // resident workgroups (no grid barrier: a wrong guess only skews load)
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     const long long total = (long long)ntm * ntn * groups;
     if (total > 0x7fffffffLL) return 0;

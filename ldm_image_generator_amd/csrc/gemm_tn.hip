@@ -149,11 +149,8 @@ extern "C" int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, lo
     const long long blocks = (long long)p.ntn * p.ntk * splits;
     LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_gemm_tn_f32: grid too large");
     constexpr size_t smem = 2ull * STAGE * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    static LdmLdsOptIn opt_in;
+    (void)opt_in((const void *)gemm_tn_kernel, smem);
     void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)N * K, (hipStream_t)stream,
                                4.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);

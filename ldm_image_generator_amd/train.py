@@ -12,6 +12,8 @@ Every GEMM-shaped gradient is an ``ldm_gemm_f32`` launch:
   weight gradient  dW = dY^T . X      -> NT GEMM over transposed activations, split along the huge reduction
                                          (pixels) into grid groups, partial sums reduced by a second kernel
 """
+import weakref
+
 import torch
 
 from . import ops, weights
@@ -44,9 +46,12 @@ class _WeightT:
     def get(self, w2d, key_tensor):
         key = weights.key(key_tensor)
         hit = self.cache.get(id(key_tensor))
-        if hit is None or hit[0] != key:
-            hit = (key, _T(w2d.contiguous()))
-            self.cache[id(key_tensor)] = hit
+        # ids (and allocator addresses) are reused after a module dies: an entry is only valid for the very object it was made for,
+        # and dies with it (weakref callback)
+        if hit is None or hit[0] != key or hit[2]() is not key_tensor:
+            kid = id(key_tensor)
+            hit = (key, _T(w2d.contiguous()), weakref.ref(key_tensor, lambda _r, kid=kid, c=self.cache: c.pop(kid, None)))
+            self.cache[kid] = hit
         return hit[1]
 
 
@@ -436,9 +441,11 @@ class _Weight16:
         # a parameter outside the refreshed network (module-level use, tests): one cast per parameter version
         key = weights.key(p)
         lone = self.lone.get(id(p))
-        if lone is None or lone[0] != key:
+        if lone is None or lone[0] != key or lone[3]() is not p:        # see _WeightT.get: entries belong to one live object
             w = _w2d(p).contiguous()
-            lone = self.lone[id(p)] = (key, ops.cast_bf16(w), ops.transpose_cast_bf16(w))
+            pid = id(p)
+            lone = self.lone[pid] = (key, ops.cast_bf16(w), ops.transpose_cast_bf16(w),
+                                     weakref.ref(p, lambda _r, pid=pid, c=self.lone: c.pop(pid, None)))
         return lone[1 + int(transposed)]
 
 

@@ -233,7 +233,14 @@ class VectorQuantizer(nn.Module):
         return ops.vq_quantize(self._rows(x), self.embeddings.detach().contiguous()).reshape(x.shape[:-1])
 
     def embed(self, x):
-        out = ops.vq_embed(x.reshape(-1).contiguous(), self.embeddings.detach().contiguous())
+        """vae.py:24-26 (F.embedding): indices -> codebook rows.  Like F.embedding an out-of-range index raises (checked on the
+        device, one host sync; this is not on the sampling hot path).  The gather is not differentiable here: the codebook's
+        gradient flows through ``calculate_loss`` only, which is the only place the reference's training loop uses it."""
+        idx = x.reshape(-1).contiguous()
+        n = self.embeddings.shape[0]
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n):
+            raise IndexError("VectorQuantizer.embed: index out of range [0, %d)" % n)
+        out = ops.vq_embed(idx, self.embeddings.detach().contiguous())
         return out.reshape(tuple(x.shape) + (self.embeddings.shape[1],))
 
 

@@ -187,10 +187,13 @@ def test_bf16_elementwise_kernels(gpu_device):
 
 
 # ------------------------------------------------------------------------------------------------------
-# whole training step in bf16 mode.  Stated tolerance (measured on MI355X against the reference's fp32 autograd, see
-# DESIGN.md): loss within 2e-3 relative; per-parameter gradient norm within 3e-2; gradient tensors rel-L2 <= 5e-2.
+# whole training step in bf16 mode.  Stated tolerance against the reference's fp32 autograd = about twice what was measured on
+# MI355X (loss 1.5e-4, worst gradient norm 3.2e-3, gradient slices 5.5e-3 ... 1.4e-2): loss within 4e-4 relative;
+# per-parameter gradient norm within 8e-3; gradient tensors rel-L2 <= 3e-2.  The small-net test compares bf16 against this
+# repo's own fp32 path on a narrow net (few terms per sum, so bf16 rounding averages out less): its bounds are stated there.
 # ------------------------------------------------------------------------------------------------------
-LOSS_TOL, NORM_TOL, GRAD_TOL = 2e-3, 3e-2, 5e-2
+LOSS_TOL, NORM_TOL, GRAD_TOL = 4e-4, 8e-3, 3e-2
+SMALL_LOSS_TOL, SMALL_GRAD_TOL = 2e-3, 5e-2
 
 
 def formula(module, gain=1.0):
@@ -223,7 +226,7 @@ def test_bf16_training_step_small_net_vs_fp32_path(gpu_device):
     l32, g32 = run("f32")
     l16, g16 = run("bf16")
     train.set_precision(net, "f32")
-    assert abs(l16 - l32) < LOSS_TOL * abs(l32)
+    assert abs(l16 - l32) < SMALL_LOSS_TOL * abs(l32)
     worst = 0.0
     for k, ref in g32.items():
         if ref is None:
@@ -231,7 +234,7 @@ def test_bf16_training_step_small_net_vs_fp32_path(gpu_device):
             continue
         err = rel_l2(g16[k], ref)
         worst = max(worst, err)
-        assert err < GRAD_TOL, (k, err)
+        assert err < SMALL_GRAD_TOL, (k, err)
     print("bf16 vs fp32 path, small net: loss %.6f vs %.6f, worst gradient rel-L2 %.3e" % (l16, l32, worst))
 
 
