@@ -295,7 +295,10 @@ int ldm_window_attention_bwd_mfma(int v);
  * ------------------------------------------------------------------------------------------------ */
 /* ldm_gemm_f32's descriptor with bf16 operands: d->a, d->w[s] point to bf16; d->lda, d->ldw, d->K, K-segment lengths and
  * the a/w group strides count bf16 elements (K, N multiples of 64; rows 16-byte addressable).  bias / addend are fp32.
- * out_bf16 == 0: d->out is fp32 [M, ldo];  != 0: d->out is bf16 [M, ldo] (no addend).  Rows in / rows out only, no gate. */
+ * out_bf16 == 0: d->out (and d->addend, if any) is fp32 [M, ldo];  != 0: d->out is bf16 [M, ldo] and d->addend, if any, is a bf16
+ * [M, ldadd] matrix added in fp32 before the one rounding (the VAE ResBlock skip of the bf16 decode mode, vae.py:65).
+ * d->a_mode == LDM_A_CONV3X3 (bf16 output only): dense 3x3, zero pad 1, over bf16 rows [M = B*H*W, Cin], Cin a multiple of 64,
+ * K = 9*Cin, weights packed [N][tap][Cin] bf16 (vae.py:57-58 under autocast).  Rows out only, no gate. */
 int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream);
 /* ReGLU forward in one launch (modules.py:14-15): d->act == LDM_ACT_GATE, d->w / d->w2 (+ bias / bias2) the "a" / "b" branches,
  * d->out = a * relu(b) as bf16 [M, ldo]; a_pre / b_pre (both or neither): bf16 [M, ldo] copies of the pre-activations a, b that
@@ -384,6 +387,45 @@ typedef struct ldm_cast_job {
 } ldm_cast_job;
 size_t ldm_multi_cast_table_bytes(int njobs);
 int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, int rebuild, long long *tiles_io, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 sampling / decode ("autocast": ddpm.py:52,75 -- on a GPU the reference runs DDPM.sample under 16-bit autocast,
+ * sample_ldm.py:17,72; fp16 overflows on these weights, so the 16-bit type here is bf16).  Opt-in; the default path is
+ * exact fp32.  GEMM operands are bf16 with fp32 accumulation; the UNet's residual stream, FiLM tables, attention core
+ * and the DDIM update stay fp32; the VAE decoder keeps its activations as bf16 rows and emits fp32 RGB planes.
+ * ------------------------------------------------------------------------------------------------ */
+/* ldm_window_attention_f32 with the fp32 QKV of a bf16 in-projection: the float "mask" source of shifted windows is the bf16
+ * normalised input xf_bf16 [B,H,W,C] (NULL allowed when shift == 0) and the context leaves as bf16 rows [B,H,W,C].  ws*ws <= 48. */
+int ldm_window_attention_bf16io(const float *qkv, const float *in_proj_bias, const void *xf_bf16, void *out_bf16,
+                                int B, int H, int W, int C, int ws, int shift, void *stream);
+/* ldm_stem_nchw_f32 with bf16 rows out (VAE Decoder.input_layer, vae.py:112,123) */
+int ldm_stem_nchw_bf16(const float *x, const float *w, const float *bias, void *out_bf16, int B, int Cin, int HW, int C0, void *stream);
+/* the scatter of ConvTranspose2d(k=2, s=2) (vae.py:120) as its own pass: in [B*H*W, 4*C] bf16 with columns (dy, dx, c)
+ * -> out [B*2H*2W, C] bf16 */
+int ldm_depth_to_space2_bf16(const void *in_bf16, void *out_bf16, int B, int H, int W, int C, void *stream);
+/* ldm_rgb_head_f32 on bf16 rows (vae.py:104,131): out / prev stay fp32 NCHW planes */
+int ldm_rgb_head_bf16(const void *x_bf16, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, void *stream);
+/* out[(b, y, x), :] = coarse[(b, y/2, x/2), :] (+ skip[(b, y, x), :]) on fp32 rows; H, W are the COARSE sizes (unet.py:85,101 split
+ * from its GEMM) */
+int ldm_up2_add_f32(const float *coarse, const float *skip, float *out, int B, int H, int W, int C, void *stream);
+/* ldm_avgpool2_f32 rounding its result once to bf16 rows (the operand of the 1x1 down conv, unet.py:83) */
+int ldm_avgpool2_bf16(const float *x, void *out_bf16, int B, int H, int W, int C, void *stream);
+
+/* bf16 copies of the GEMM weights of a ldm_unet_plan, block by block in the plan's order: grouped conv packed [C][tap][32],
+ * ReGLU a / b / c [C, C], in_proj [3C, C], out_proj [C, C] (NULL where the block has no attention). */
+typedef struct ldm_unet_block_bf16 {
+    const void *conv_w;
+    const void *a_w[5], *b_w[5], *c_w[5];
+    const void *in_w, *out_w;
+} ldm_unet_block_bf16;
+typedef struct ldm_unet_plan_bf16 {
+    int nblocks;
+    const ldm_unet_block_bf16 *blocks;       /* HOST array, execution order */
+} ldm_unet_plan_bf16;
+/* ldm_unet_forward_ex_f32 in the bf16 mode (same workspace size, same arguments); every stage width must be a multiple of 64 */
+int ldm_unet_forward_bf16(const ldm_unet_plan *plan, const ldm_unet_plan_bf16 *plan16, const float *x, const long long *t_unique, int nT,
+                          const int *slot, const int *decisions, int B, int H, int W, void *workspace, size_t workspace_bytes, float *out,
+                          int films_ready, void *stream);
 
 #ifdef __cplusplus
 }

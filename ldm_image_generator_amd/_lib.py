@@ -73,6 +73,16 @@ class UNetPlanDesc(ctypes.Structure):
                 ("blocks", ctypes.POINTER(UNetBlockDesc))]
 
 
+class UNetBlock16Desc(ctypes.Structure):
+    """struct ldm_unet_block_bf16"""
+    _fields_ = [("conv_w", c_fp), ("a_w", c_fp * 5), ("b_w", c_fp * 5), ("c_w", c_fp * 5), ("in_w", c_fp), ("out_w", c_fp)]
+
+
+class UNetPlan16Desc(ctypes.Structure):
+    """struct ldm_unet_plan_bf16"""
+    _fields_ = [("nblocks", ctypes.c_int), ("blocks", ctypes.POINTER(UNetBlock16Desc))]
+
+
 class CastJob(ctypes.Structure):
     """struct ldm_cast_job"""
     _fields_ = [("src", c_fp), ("dst", c_fp), ("dst_t", c_fp), ("rows", ctypes.c_longlong), ("cols", ctypes.c_int)]
@@ -161,6 +171,15 @@ SIGNATURES = {
     "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_film_hidden_bwd_chunks": (_I, [_I, _I, _I]),
     "ldm_film_hidden_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    # bf16 sampling / decode
+    "ldm_window_attention_bf16io": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_stem_nchw_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_depth_to_space2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_rgb_head_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_up2_add_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_avgpool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_unet_forward_bf16": (_I, [ctypes.POINTER(UNetPlanDesc), ctypes.POINTER(UNetPlan16Desc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I,
+                                   _P, ctypes.c_size_t, _P, _I, _P]),
 }
 
 _lib = None

@@ -15,6 +15,10 @@ namespace {
 struct AttnP {
     const float *qkv, *bias, *xf;
     float *out;
+    // bf16 sampling (autocast): the context leaves as bf16 rows (the out-projection's GEMM operand) and the float "mask" of shifted
+    // windows (attention.py:40) is read from the bf16 copy of the normalised input; the attention arithmetic itself stays fp32
+    unsigned short *out16;
+    const unsigned short *xf16;
     int B, H, W, C, ws, shift;
     int Hp, Wp, nwh, nww, heads, L;
     int global;     // H<=ws && W<=ws: one window of H*W tokens, no mask
@@ -234,7 +238,12 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const AttnP 
                         int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
                         my += my < 0 ? p.Hp : 0;
                         mx += mx < 0 ? p.Wp : 0;
-                        kb = (my < p.H && mx < p.W) ? p.xf[(img + (long long)my * p.W + mx) * C] : 0.f;
+                        if (my < p.H && mx < p.W) {
+                            const long long mi = (img + (long long)my * p.W + mx) * C;
+                            kb = p.xf16 ? __uint_as_float((unsigned)p.xf16[mi] << 16) : p.xf[mi];
+                        } else {
+                            kb = 0.f;
+                        }
                     }
                 }
             }
@@ -310,24 +319,54 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const AttnP 
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt)
         if (qok[qt]) {                          // padded queries are cropped (attention.py:59)
-            float *dst = p.out + orow[qt] + 4 * g;
-            *(f32x4 *)dst = o[qt][0];
-            *(f32x4 *)(dst + 16) = o[qt][1];
+            if (p.out16) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+                unsigned short *dst = p.out16 + orow[qt] + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x2v lo = {o[qt][dt][0], o[qt][dt][1]}, hi = {o[qt][dt][2], o[qt][dt][3]};
+                    *(u32x2 *)(dst + 16 * dt) = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2v)),
+                                                      __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2v))};
+                }
+            } else {
+                float *dst = p.out + orow[qt] + 4 * g;
+                *(f32x4 *)dst = o[qt][0];
+                *(f32x4 *)(dst + 16) = o[qt][1];
+            }
         }
 }
 
 }  // namespace
 
+static int window_attention_impl(const float *qkv, const float *in_proj_bias, const float *xf, const void *xf16, float *out, void *out16, int B, int H,
+                                 int W, int C, int ws, int shift, void *stream);
+
 extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_bias, const float *xf, float *out, int B, int H,
                                         int W, int C, int ws, int shift, void *stream)
 {
-    LDM_REQUIRE(qkv && in_proj_bias && out, "ldm_window_attention_f32: null pointer");
+    return window_attention_impl(qkv, in_proj_bias, xf, nullptr, out, nullptr, B, H, W, C, ws, shift, stream);
+}
+
+extern "C" int ldm_window_attention_bf16io(const float *qkv, const float *in_proj_bias, const void *xf_bf16, void *out_bf16, int B, int H,
+                                           int W, int C, int ws, int shift, void *stream)
+{
+    LDM_REQUIRE(out_bf16 && (((size_t)out_bf16) & 7) == 0, "ldm_window_attention_bf16io: null / unaligned output");
+    return window_attention_impl(qkv, in_proj_bias, nullptr, xf_bf16, nullptr, out_bf16, B, H, W, C, ws, shift, stream);
+}
+
+static int window_attention_impl(const float *qkv, const float *in_proj_bias, const float *xf, const void *xf16, float *out, void *out16, int B, int H,
+                                 int W, int C, int ws, int shift, void *stream)
+{
+    LDM_REQUIRE(qkv && in_proj_bias && (out || out16), "ldm_window_attention_f32: null pointer");
     LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0, "ldm_window_attention_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     LDM_REQUIRE(ws >= 1 && ws <= 8, "ldm_window_attention_f32: window_size=%d unsupported (1..8)", ws);
     LDM_REQUIRE(shift >= 0 && shift < ws, "ldm_window_attention_f32: shift=%d", shift);
-    LDM_REQUIRE(ldm_aligned16(qkv) && ldm_aligned16(in_proj_bias) && ldm_aligned16(out), "ldm_window_attention_f32: unaligned pointer");
+    LDM_REQUIRE(ldm_aligned16(qkv) && ldm_aligned16(in_proj_bias) && (!out || ldm_aligned16(out)), "ldm_window_attention_f32: unaligned pointer");
     AttnP p{};
     p.qkv = qkv; p.bias = in_proj_bias; p.xf = xf; p.out = out;
+    p.out16 = (unsigned short *)out16; p.xf16 = (const unsigned short *)xf16;
     p.B = B; p.H = H; p.W = W; p.C = C; p.ws = ws; p.shift = shift;
     p.heads = C / 32;
     p.global = (H <= ws && W <= ws) ? 1 : 0;
@@ -337,7 +376,7 @@ extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_b
         p.Hp = (H + ws - 1) / ws * ws;                       // attention.py:21-25
         p.Wp = (W + ws - 1) / ws * ws;
         p.nwh = p.Hp / ws; p.nww = p.Wp / ws; p.L = ws * ws;
-        LDM_REQUIRE(shift == 0 || xf != nullptr, "ldm_window_attention_f32: shift != 0 needs xf (float mask source)");
+        LDM_REQUIRE(shift == 0 || xf != nullptr || xf16 != nullptr, "ldm_window_attention_f32: shift != 0 needs xf (float mask source)");
     }
     p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
     const unsigned blocks = (unsigned)((p.total_waves + 3) / 4);

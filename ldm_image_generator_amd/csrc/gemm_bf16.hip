@@ -9,7 +9,7 @@
 
 using namespace ldmgemm;
 
-int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate);
+int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate, int amode);
 int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st);      // gemm_ring.hip: 256-row tiles, one workgroup per CU, four-stage ring
 int ldm_gemm_ring_dispatch_bf16_gate(const GemmP &p, int groups, hipStream_t st);
 
@@ -22,7 +22,12 @@ int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mo
     LDM_REQUIRE(d != nullptr && d->a && d->out, "%s: null descriptor / operand", who);
     LDM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->N % 64 == 0 && d->K % 64 == 0, "%s: M=%d, N=%d and K=%d must be positive multiples of (1, 64, 64)", who,
                 d->M, d->N, d->K);
-    LDM_REQUIRE(d->a_mode == LDM_A_ROWS && d->o_mode == LDM_O_ROWS && !d->w_table, "%s: rows in / rows out, no pointer table", who);
+    const bool conv = d->a_mode == LDM_A_CONV3X3;        // dense 3x3 (VAE decode under autocast): implicit im2col of bf16 rows [M, Cin]
+    LDM_REQUIRE((d->a_mode == LDM_A_ROWS || (conv && mode == 0)) && d->o_mode == LDM_O_ROWS && !d->w_table, "%s: rows (or 3x3 taps) in / rows out, no pointer table", who);
+    if (conv) {
+        LDM_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 64 == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && out_bf16,
+                    "%s: conv3x3 needs K == 9*Cin, Cin %% 64 == 0, M %% (H*W) == 0 and the bf16 output", who);
+    }
     LDM_REQUIRE((d->act == LDM_ACT_GATE) == (mode == 1), "%s: act=%d does not fit this entry point", who, d->act);
     LDM_REQUIRE(d->nseg >= 1 && d->nseg <= LDM_MAX_SEG && (d->seg_mode == LDM_SEG_N || d->seg_mode == LDM_SEG_K), "%s: nseg=%d seg_mode=%d", who, d->nseg,
                 d->seg_mode);
@@ -38,7 +43,9 @@ int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mo
         LDM_REQUIRE(d->w[s] && ldm_aligned16(d->w[s]), "%s: weight segment %d null/unaligned", who, s);
         if (mode == 1) LDM_REQUIRE(d->w2[s] && ldm_aligned16(d->w2[s]), "%s: gate weight segment %d null/unaligned", who, s);
     }
-    LDM_REQUIRE(!(out_bf16 && d->addend), "%s: an addend needs the fp32 output", who);
+    // an addend has the output's element type: fp32 [M, ldadd] with the fp32 output, bf16 [M, ldadd] with the bf16 output
+    LDM_REQUIRE(!(out_bf16 && d->addend && mode), "%s: the fused gate forms take no addend", who);
+    if (out_bf16 && d->addend) LDM_REQUIRE((((size_t)d->addend) & 7) == 0 && d->ldadd % 4 == 0, "%s: bf16 addend must be 8-byte addressable", who);
     if (out_bf16) LDM_REQUIRE((((size_t)d->out) & 7) == 0 && d->ldo % 4 == 0 && d->o_gstride % 4 == 0, "%s: bf16 output must be 8-byte addressable", who);
     if (mode) {
         LDM_REQUIRE(out_bf16 && groups == 1, "%s: the fused gate forms write bf16 and take one group", who);
@@ -48,6 +55,7 @@ int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mo
     GemmP p{};
     p.a = d->a; p.lda = d->lda / 2; p.M = d->M; p.N = d->N; p.K = d->K / 2;          // K axis in 4-byte units from here on
     p.cpt = 1;
+    if (conv) { p.H = d->H; p.W = d->W; p.Cin = d->Cin / 2; p.cpt = d->Cin / 64; }      // a K-step is 64 bf16 channels of one tap
     p.nseg = d->nseg; p.seg_mode = d->seg_mode;
     p.seg_len = d->seg_mode == LDM_SEG_K ? seg_len / 2 : seg_len;
     for (int s = 0; s < LDM_MAX_SEG; ++s) {
@@ -57,7 +65,8 @@ int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mo
         p.bias2[s] = (mode == 1 && s < d->nseg) ? d->bias2[s] : nullptr;
     }
     p.ldw = d->ldw / 2; p.act = d->act; p.slope = d->slope;
-    p.addend = d->addend; p.ldadd = d->ldadd; p.out = d->out; p.ldo = d->ldo;
+    p.addend = out_bf16 ? nullptr : d->addend; p.addend16 = out_bf16 ? (const void *)d->addend : nullptr;
+    p.ldadd = d->ldadd; p.out = d->out; p.ldo = d->ldo;
     p.o_mode = LDM_O_ROWS;
     p.a_gstride = d->a_gstride / 2; p.w_gstride = d->w_gstride / 2; p.o_gstride = d->o_gstride; p.b_gstride = d->b_gstride;
     p.wide_ok = out_bf16 ? 1
@@ -67,10 +76,13 @@ int gemm_bf16_impl(const char *who, const ldm_gemm_desc *d, int out_bf16, int mo
     hipStream_t st = (hipStream_t)stream;
     const double mn = (double)d->M * d->N * groups;
     const double out_planes = mode == 1 ? (x1 ? 3.0 : 1.0) : (mode == 2 ? 2.0 : 1.0);
+    const double a_cols = conv ? d->Cin : d->K;                 // algorithmic bytes: every operand element once (im2col re-reads are not algorithmic)
     void *rec = ldm_prof_begin(LDM_PROF_GEMM_BF16, 2.0 * mn * d->K * (mode == 1 ? 2.0 : 1.0), st,
-                               2.0 * ((double)d->M * d->K * (d->a_gstride || groups == 1 ? groups : 1) + (double)d->N * d->K * groups * (mode == 1 ? 2.0 : 1.0)) +
-                                   mn * (out_bf16 ? 2.0 : 4.0) * out_planes + (mode == 2 ? mn * 4.0 : 0.0) + (d->addend ? mn * 4.0 : 0.0));
-    const int ok = (mode == 0 && ldm_gemm_ring_dispatch_bf16(p, groups, out_bf16 != 0, st)) || (mode == 1 && ldm_gemm_ring_dispatch_bf16_gate(p, groups, st)) || ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st, mode == 1);
+                               2.0 * ((double)d->M * a_cols * (d->a_gstride || groups == 1 ? groups : 1) + (double)d->N * d->K * groups * (mode == 1 ? 2.0 : 1.0)) +
+                                   mn * (out_bf16 ? 2.0 : 4.0) * out_planes + (mode == 2 ? mn * 4.0 : 0.0) + (d->addend ? mn * (out_bf16 ? 2.0 : 4.0) : 0.0));
+    const bool ring_ok = !conv && !p.addend16;
+    const int ok = (ring_ok && mode == 0 && ldm_gemm_ring_dispatch_bf16(p, groups, out_bf16 != 0, st)) || (ring_ok && mode == 1 && ldm_gemm_ring_dispatch_bf16_gate(p, groups, st)) ||
+                   ldm_gemm_stream_dispatch_bf16(p, groups, out_bf16 != 0, st, mode == 1, d->a_mode);
     ldm_prof_end(rec, st);
     LDM_REQUIRE(ok, "%s: no kernel instance for this shape (N=%d, seg_len=%d)", who, d->N, seg_len);
     LDM_CHECK_LAUNCH(who);

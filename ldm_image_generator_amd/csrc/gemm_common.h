@@ -35,6 +35,9 @@ struct GemmP {
     //   gate backward: the GEMM result is dh; in2 = a, in3 = b;  out = dh * relu(b),  out2 = dh * a * (b > 0)
     void *out2, *out3;
     const void *in2, *in3;
+    // bf16 sampling / decode: a bf16 addend [M, ldadd] for the bf16 output of the wide epilogue (VAE ResBlock skip: vae.py:65),
+    // added in fp32 after the activation, before the one rounding to bf16
+    const void *addend16;
 };
 
 // 64 B of zeros (one copy per translation unit): target of "absent operand" loads, so that optional
@@ -370,8 +373,22 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
             }
         };
         if (gate_bwd) load_ab(0);
+        const bool add16 = OBF && !GATE && !gate_bwd && p.addend16 != nullptr;
 #pragma unroll
         for (int im = 0; im < TM; ++im) {
+            // bf16 addend of this strip (4 TN row pieces of 4 columns): issued before the strip's LDS round trip, consumed after it
+            u32x2_t a16[4 * TN];
+            if constexpr (OBF && !GATE) {
+                if (add16) {
+                    const unsigned short *ab = (const unsigned short *)p.addend16 + (long long)row0 * p.ldadd + g * p.o_gstride + n0 + wn * TN * 32 + 4 * wl.cc;
+#pragma unroll
+                    for (int k = 0; k < 4 * TN; ++k) {
+                        int roff = im * 32 + k * RPI;
+                        if (!full && row0 + roff >= p.M) roff = p.M - 1 - row0;
+                        a16[k] = *(const u32x2_t *)(ab + (long long)roff * p.ldadd);
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
 #pragma unroll
@@ -446,6 +463,14 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
                             *(u32x2_t *)((unsigned short *)p.out2 + oelem + (long long)roff * ldo_) =
                                 u32x2_t{pack_bf16x2(db[0], db[1]), pack_bf16x2(db[2], db[3])};
                         } else {
+                            if constexpr (!GATE) {
+                                if (add16) {
+                                    v[0] += __uint_as_float(a16[k][0] << 16);
+                                    v[1] += __uint_as_float(a16[k][0] & 0xFFFF0000u);
+                                    v[2] += __uint_as_float(a16[k][1] << 16);
+                                    v[3] += __uint_as_float(a16[k][1] & 0xFFFF0000u);
+                                }
+                            }
                             *(u32x2_t *)(ob16 + roff * ldo_) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                         }
                     } else {

@@ -71,7 +71,8 @@ __device__ __forceinline__ float ring_gload(const float *ptr)
 
 // ET: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 bf16 (v_mfma_f32_32x32x16_bf16); NJ: accumulator columns per wave (tile = 256 x 128 NJ);
 // GATE (NJ == 2): tile = 256 x 128 hidden columns; OBF: bf16 output (ET == 1, NJ == 2, plain)
-template <int ET, int NJ, bool GATE, bool OBF, bool ADD, bool GF = false>
+// GF (bf16 gated instance): 0 fp32 output, 1 bf16 hidden only (sampling), 3 bf16 hidden + both pre-activations (training forward)
+template <int ET, int NJ, bool GATE, bool OBF, bool ADD, int GF = 0>
 __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     static_assert(!GATE || NJ == 2, "gate: two accumulator columns (a, b)");
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     constexpr int RPW = 2 + NJ;                                    // LDS-DMA instructions per wave and step (2 x A, NJ x W)
     constexpr int NM = (ET ? 1 : 4) * 4 * NJ;                      // MFMAs of one slice
     static_assert(!GF || (ET == 1 && GATE && !OBF && !ADD), "bf16 gate forward with saved pre-activations: the gated bf16 instance");
-    constexpr int NSTORE = GF ? 48 : (OBF || GATE) ? 16 : 16 * NJ;  // row stores per wave and tile in the epilogue
+    constexpr int NSTORE = GF ? 16 * GF : (OBF || GATE) ? 16 : 16 * NJ;  // row stores per wave and tile in the epilogue
     constexpr int NBIAS = GATE ? 2 : 4 * NJ;                       // bias loads per lane and tile (issued at the tile's start)
     extern __shared__ __attribute__((aligned(16))) char rlds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int pass = 0; pass < 3; ++pass) {
+                    for (int pass = 0; pass < GF; ++pass) {
                         unsigned short *o16 = (unsigned short *)(pass == 0 ? p.out : (pass == 1 ? p.out2 : p.out3));
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int ET, int NJ, bool GATE, bool OBF, bool ADD = false, bool GF = false>
+template <int ET, int NJ, bool GATE, bool OBF, bool ADD = false, int GF = 0>
 int ring_launch(const GemmP &p, hipStream_t st)
 {
     static LdmLdsOptIn opt_in;                               // per device: a device that refuses 160 KiB of LDS per workgroup falls back to the stream kernel
@@ -475,8 +476,8 @@ int ring_launch(const GemmP &p, hipStream_t st)
 // the problem should run with, or 0 if the ring kernel does not take it
 int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32, bool gate_fwd = false)
 {
-    if (g_ring == 0 || groups != 1 || p.use_table || p.in2) return 0;
-    if (gate_fwd ? !(p.out2 && p.out3) : (p.out2 != nullptr)) return 0;
+    if (g_ring == 0 || groups != 1 || p.use_table || p.in2 || p.addend16) return 0;
+    if (gate_fwd ? ((p.out2 != nullptr) != (p.out3 != nullptr)) : (p.out2 != nullptr)) return 0;
     if (p.M % RT || (p.K & 15) || p.K < 16) return 0;
     if (p.seg_mode == LDM_SEG_K && p.nseg > 1 && (p.seg_len & 15)) return 0;
     if (p.lda * 4 * RT >= (1ll << 31) || p.ldw * 4 * RT >= (1ll << 31)) return 0;
@@ -523,9 +524,10 @@ int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipSt
 // bf16 ReGLU forward with saved pre-activations (ldm_gemm_bf16_gate_fwd): returns 1 if the ring kernel launched
 int ldm_gemm_ring_dispatch_bf16_gate(const GemmP &p, int groups, hipStream_t st)
 {
-    if (!p.out2 || !p.out3 || p.addend || p.ldo % 4 || (((size_t)p.out | (size_t)p.out2 | (size_t)p.out3) & 7)) return 0;
+    if (p.addend || p.ldo % 4 || (((size_t)p.out | (size_t)p.out2 | (size_t)p.out3) & 7)) return 0;
     if (ring_shape(p, groups, true, false, false, true) != 2) return 0;
-    return ring_launch<1, 2, true, false, false, true>(p, st);
+    if (!p.out2) return ring_launch<1, 2, true, false, false, 1>(p, st);          // hidden only (sampling: nothing is kept for a backward)
+    return ring_launch<1, 2, true, false, false, 3>(p, st);
 }
 
 // exact fp32 (ldm_gemm_f32: rows in, rows out, plain or gated): returns 1 if the ring kernel launched

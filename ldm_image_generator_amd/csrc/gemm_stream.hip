@@ -515,9 +515,16 @@ int ldm_gemm_stream_dispatch(const GemmP &p, int groups, bool gate, int amode, h
 
 
 // bf16 operands (ldm_gemm_bf16): plain rows in, rows out (fp32 or bf16); p is already in 4-byte units along K.
-int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate)
+int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st, bool gate, int amode)
 {
     const int unit = (p.seg_mode == LDM_SEG_N) ? p.seg_len : p.N;
+    if (amode == LDM_A_CONV3X3) {        // dense 3x3 of the VAE in bf16 (decode under autocast): implicit im2col in the loader, bf16 rows out
+        if (gate || !out_bf16 || !p.wide_ok) return 0;
+        if (unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512)
+            return launch_stream<2, 2, 2, 2, false, LDM_A_CONV3X3, 0, true, 1, true>(p, groups, st);
+        if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_CONV3X3, 0, true, 1, true>(p, groups, st);
+        return 0;
+    }
     if (gate) {          // a * relu(b) from two weight matrices per tile (128 x 64 x 2), bf16 out (+ the saved pre-activations)
         if (!out_bf16 || unit % 64) return 0;
         return launch_stream<2, 2, 2, 1, true, LDM_A_ROWS, 0, true, 1, true>(p, groups, st);

@@ -13,6 +13,7 @@
 extern "C" {
 int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
 }
+// (every other entry point the executor calls is declared in include/ldm_hip.h, which common.h includes)
 
 namespace {
 
@@ -116,6 +117,55 @@ void allow_splitk(ldm_gemm_desc &d, const Layout &L)
     }
 }
 
+// bf16 GEMM problem: rows of bf16 in, one bf16 weight segment; everything else as gemm_rows
+ldm_gemm_desc gemm_rows16(const void *a, long long M, int N, int K, const void *w, const float *bias, void *out)
+{
+    ldm_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.a = (const float *)a; d.lda = K; d.M = (int)M; d.N = N; d.K = K;
+    d.nseg = 1; d.w[0] = (const float *)w; d.bias[0] = bias; d.ldw = K;
+    d.out = (float *)out; d.ldo = N; d.ldadd = N; d.groups = 1;
+    return d;
+}
+
+// one SwinBlock in the bf16 ("autocast") sampling mode: the residual stream x / y stays fp32; ChannelNorm + FiLM rounds its result
+// ONCE to bf16 (the operand of the grouped conv, the in-projection and the gated GEMM); every GEMM accumulates in fp32; the gated
+// hidden and the attention context are bf16 rows; the attention core (softmax, float "mask") computes in fp32 on the fp32 QKV.
+int run_block_bf16(const ldm_unet_plan *pl, const ldm_unet_block *bk, const ldm_unet_block_bf16 *b16, int decision, const float *film, const int *slot,
+                   const float *x, float *y, const Level &lv, int B, const Layout &L, void *st)
+{
+    const int C = lv.C;
+    const long long M = lv.M;
+    void *xf16 = L.xf, *hid16 = L.hidden, *ctx16 = L.ctx;
+    RUN(ldm_channelnorm_film_bf16(x, film, slot, nullptr, xf16, B, lv.H * lv.W, C, pl->eps, st));
+    RUN(ldm_gconv3x3_bf16(xf16, b16->conv_w, bk->conv_b, x, y, B, lv.H, lv.W, C, st));           // y = conv3x3_grouped(xf) + bias + x
+    if (bk->attention) {
+        ldm_gemm_desc q = gemm_rows16(xf16, M, 3 * C, C, b16->in_w, bk->in_b, L.qkv);
+        RUN(ldm_gemm_bf16(&q, 0, st));
+        RUN(ldm_window_attention_bf16io(L.qkv, bk->in_b, xf16, ctx16, B, lv.H, lv.W, C, pl->window, bk->shift, st));
+        ldm_gemm_desc o = gemm_rows16(ctx16, M, C, C, b16->out_w, bk->out_b, y);
+        o.addend = y; o.ldadd = C;
+        RUN(ldm_gemm_bf16(&o, 0, st));
+    }
+    const int e1 = decision >> 2, e2 = decision & 3;
+    const int sel[3] = {0, 1 + e1, 1 + e2};
+    {
+        ldm_gemm_desc g = gemm_rows16(xf16, M, 3 * C, C, nullptr, nullptr, hid16);
+        g.nseg = 3; g.seg_mode = LDM_SEG_N; g.seg_len = C; g.act = LDM_ACT_GATE;
+        for (int s = 0; s < 3; ++s) {
+            g.w[s] = (const float *)b16->a_w[sel[s]]; g.bias[s] = bk->a_b[sel[s]];
+            g.w2[s] = (const float *)b16->b_w[sel[s]]; g.bias2[s] = bk->b_b[sel[s]];
+        }
+        RUN(ldm_gemm_bf16_gate_fwd(&g, nullptr, nullptr, st));
+        ldm_gemm_desc c = gemm_rows16(hid16, M, C, 3 * C, nullptr, nullptr, y);
+        c.nseg = 3; c.seg_mode = LDM_SEG_K; c.seg_len = C; c.ldw = C;
+        for (int s = 0; s < 3; ++s) { c.w[s] = (const float *)b16->c_w[sel[s]]; c.bias[s] = bk->c_b[sel[s]]; }
+        c.addend = y; c.ldadd = C;
+        RUN(ldm_gemm_bf16(&c, 0, st));
+    }
+    return LDM_OK;
+}
+
 // one SwinBlock (unet.py:42-47) on channels-last rows; y may not alias x
 int run_block(const ldm_unet_plan *pl, const ldm_unet_block *bk, int decision, const float *film, const int *slot, const float *x,
               float *y, const Level &lv, int B, const Layout &L, void *st)
@@ -173,9 +223,27 @@ extern "C" size_t ldm_unet_workspace_bytes(const ldm_unet_plan *pl, int B, int H
     return b.off;
 }
 
+static int unet_forward_impl(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *p16, const float *x, const long long *t_unique, int nT, const int *slot,
+                             const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, int films_ready, void *st);
+
 extern "C" int ldm_unet_forward_ex_f32(const ldm_unet_plan *pl, const float *x, const long long *t_unique, int nT, const int *slot,
                                        const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, int films_ready,
-                                       void *st);
+                                       void *st)
+{
+    return unet_forward_impl(pl, nullptr, x, t_unique, nT, slot, decisions, B, H, W, workspace, ws_bytes, out, films_ready, st);
+}
+
+// The same forward in the bf16 ("autocast", ddpm.py:52,75) mode: `p16` holds bf16 copies of the GEMM weights (grouped conv packed like
+// the fp32 plan's).  FiLM tables, stem, head and the ch_convs stay fp32; so does the residual stream.  Workspace: ldm_unet_workspace_bytes.
+extern "C" int ldm_unet_forward_bf16(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *p16, const float *x, const long long *t_unique, int nT,
+                                     const int *slot, const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out,
+                                     int films_ready, void *st)
+{
+    LDM_REQUIRE(p16 && p16->blocks && pl && p16->nblocks == pl->nblocks, "ldm_unet_forward_bf16: bf16 plan missing or of another size");
+    for (int i = 0; i < pl->levels; ++i) LDM_REQUIRE(pl->channels[i] % 64 == 0, "ldm_unet_forward_bf16: stage width %d is not a multiple of 64", pl->channels[i]);
+    LDM_REQUIRE(pl->window * pl->window <= 48, "ldm_unet_forward_bf16: window %d too large for the MFMA attention kernel", pl->window);
+    return unet_forward_impl(pl, p16, x, t_unique, nT, slot, decisions, B, H, W, workspace, ws_bytes, out, films_ready, st);
+}
 
 extern "C" int ldm_unet_forward_f32(const ldm_unet_plan *pl, const float *x, const long long *t_unique, int nT, const int *slot,
                                     const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, void *st)
@@ -186,9 +254,8 @@ extern "C" int ldm_unet_forward_f32(const ldm_unet_plan *pl, const float *x, con
 // films_ready != 0: the FiLM tables of (t_unique, nT) are already in this workspace from an earlier call with the same plan, shapes and
 // timesteps (the denoise loop computes them for ALL its timesteps in the first step -- they depend on t, never on x -- and every step
 // then selects its rows through `slot`); the caller owns that guarantee.
-extern "C" int ldm_unet_forward_ex_f32(const ldm_unet_plan *pl, const float *x, const long long *t_unique, int nT, const int *slot,
-                                       const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, int films_ready,
-                                       void *st)
+static int unet_forward_impl(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *p16, const float *x, const long long *t_unique, int nT, const int *slot,
+                             const int *decisions, int B, int H, int W, void *workspace, size_t ws_bytes, float *out, int films_ready, void *st)
 {
     LDM_REQUIRE(pl && x && t_unique && decisions && workspace && out, "ldm_unet_forward_f32: null pointer");
     LDM_REQUIRE(B > 0 && nT > 0, "ldm_unet_forward_f32: bad batch");
@@ -235,7 +302,8 @@ extern "C" int ldm_unet_forward_ex_f32(const ldm_unet_plan *pl, const float *x, 
             const int dcs = decisions[enc0[i] + k];
             if (dcs < 0) continue;                                          // stochastic depth (unet.py:39-40)
             const int nxt = (cur[i] + 1) % 3;
-            RUN(run_block(pl, pl->blocks + enc0[i] + k, dcs, film_of(i, k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
+            if (p16) RUN(run_block_bf16(pl, pl->blocks + enc0[i] + k, p16->blocks + enc0[i] + k, dcs, film_of(i, k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
+            else RUN(run_block(pl, pl->blocks + enc0[i] + k, dcs, film_of(i, k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
             cur[i] = nxt;
         }
         skip_buf[i] = cur[i];
@@ -260,7 +328,8 @@ extern "C" int ldm_unet_forward_ex_f32(const ldm_unet_plan *pl, const float *x, 
             const int dcs = decisions[dec0[i] + k];
             if (dcs < 0) continue;
             const int nxt = (cur[i] + 1) % 3;
-            RUN(run_block(pl, pl->blocks + dec0[i] + k, dcs, film_of(i, pl->enc_blocks[i] + k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
+            if (p16) RUN(run_block_bf16(pl, pl->blocks + dec0[i] + k, p16->blocks + dec0[i] + k, dcs, film_of(i, pl->enc_blocks[i] + k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
+            else RUN(run_block(pl, pl->blocks + dec0[i] + k, dcs, film_of(i, pl->enc_blocks[i] + k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
             cur[i] = nxt;
         }
     }

@@ -9,8 +9,11 @@ kernel that rounds exactly like the reference's separate torch ops.
 Differences, all deliberate and documented in DESIGN.md:
   * ``model=None`` builds a fresh ``UNet()`` per instance (the reference evaluates
     ``UNet()`` once at import and shares it between instances, ddpm.py:16);
-  * ``use_autocast`` is accepted and ignored: the HIP path always computes in
-    fp32, which is what the reference's CPU path does (ddpm.py:75 is a no-op there);
+  * ``use_autocast`` selects reduced precision only after an explicit opt-in
+    (``autocast.set_autocast_dtype(unet, torch.bfloat16)``): the default stays exact
+    fp32, which is what the reference's CPU path computes (ddpm.py:75 is a no-op
+    there); with the opt-in, ``use_autocast=True`` runs every UNet forward of the loop
+    with bf16 GEMM operands (fp32 accumulate, fp32 residual stream, fp32 DDIM update);
   * ``sample(..., x_init=)`` optionally injects x_T (parity tests need a
     CPU-generated start; the reference draws it on the model's device).
 """
@@ -81,6 +84,10 @@ class DDPM(nn.Module):
         hint_ok = hasattr(self.model, "_uniform_time")
         if hasattr(self.model, "_films_key"):
             self.model._films_key = None
+        # ddpm.py:75 `with torch.cuda.amp.autocast(enabled=use_autocast)`: honoured when the model has opted into a 16-bit type
+        amp = bool(use_autocast) and getattr(self.model, "autocast_dtype", None) is not None
+        if amp:
+            self.model._autocast_now = True
         t_dev = torch.tensor([int(s) for s in steps], dtype=torch.int64, device=device)   # one upload for the whole loop
         try:
             for i, (t, t_next) in enumerate(zip(reversed(steps), reversed(steps_next))):
@@ -105,6 +112,8 @@ class DDPM(nn.Module):
                 ops.ddim_update(x, e_theta, e, float(s1), float(s2), float(s3), float(s4), float(sigma), t == 0)
                 bar.update(1)
         finally:
+            if amp:
+                self.model._autocast_now = False
             if hint_ok:
                 self.model._uniform_time = None
                 if hasattr(self.model, "_films_key"):

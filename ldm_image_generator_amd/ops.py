@@ -357,14 +357,18 @@ BF16 = torch.bfloat16
 
 
 def gemm_bf16(a, M, N, K, weights, out, *, lda=None, ldo=None, biases=None, ldw=None, seg_mode=SEG_N, act=ACT_NONE, slope=0.0,
-              addend=None, ldadd=None):
-    """out = act(A . W^T + bias) (+ addend) with bf16 A and W (fp32 accumulate); ``out`` is fp32 or bf16 by its dtype."""
+              addend=None, ldadd=None, a_mode=A_ROWS, conv_hw=None, cin=0):
+    """out = act(A . W^T + bias) (+ addend) with bf16 A and W (fp32 accumulate); ``out`` is fp32 or bf16 by its dtype and an
+    addend has the output's dtype.  ``a_mode=A_CONV3X3`` (bf16 out): dense 3x3 over bf16 rows [M, cin], K = 9 * cin."""
     lib = _lib.load()
     d = GemmDesc()
     d.a = _dev(a, "a", BF16)
-    d.lda = K if lda is None else lda
+    d.lda = (cin if a_mode == A_CONV3X3 else K) if lda is None else lda
     d.M, d.N, d.K = M, N, K
-    d.a_mode = A_ROWS
+    d.a_mode = a_mode
+    if conv_hw is not None:
+        d.H, d.W = conv_hw
+    d.Cin = cin
     nseg = len(weights)
     d.nseg, d.seg_mode = nseg, seg_mode
     d.seg_len = (N if seg_mode == SEG_N else K) // nseg
@@ -374,9 +378,9 @@ def gemm_bf16(a, M, N, K, weights, out, *, lda=None, ldo=None, biases=None, ldw=
             d.bias[s] = _dev(biases[s], "bias")
     d.ldw = (K if seg_mode == SEG_N else K // nseg) if ldw is None else ldw
     d.act, d.slope = act, slope
-    d.addend = _opt(addend, "addend")
-    d.ldadd = N if ldadd is None else ldadd
     out_bf16 = out.dtype == BF16
+    d.addend = _opt(addend, "addend", BF16 if out_bf16 else torch.float32)
+    d.ldadd = N if ldadd is None else ldadd
     d.out = _dev(out, "out", BF16 if out_bf16 else torch.float32)
     d.ldo = N if ldo is None else ldo
     d.o_mode = O_ROWS
@@ -570,3 +574,38 @@ def film_hidden_bwd(dh, hid, B, HW, N):
     dp = dp_part[0] if z == 1 else reduce_partials(dp_part, z, HW * N, torch.empty(HW, N, device=dev, dtype=torch.float32))
     dtt = dt_part[0] if ptiles == 1 else reduce_partials(dt_part, ptiles, B * N, torch.empty(B, N, device=dev, dtype=torch.float32))
     return dp, dtt
+
+
+# ---- bf16 sampling / decode (include/ldm_hip.h, "bf16 sampling / decode") ------------------------------------
+def window_attention_bf16io(qkv, in_proj_bias, xf16, out16, B, H, W, C, ws, shift):
+    """window_attention on the fp32 QKV of a bf16 in-projection: float "mask" read from the bf16 normalised input, bf16 context out."""
+    _call("ldm_window_attention_bf16io", _dev(qkv, "qkv"), _dev(in_proj_bias, "in_proj_bias"), _opt(xf16, "xf16", BF16), _dev(out16, "out", BF16),
+          B, H, W, C, ws, shift)
+    return out16
+
+
+def stem_nchw_bf16(x, w, bias, out16, B, Cin, HW, C0):
+    _call("ldm_stem_nchw_bf16", _dev(x, "x"), _dev(w, "w"), _opt(bias, "bias"), _dev(out16, "out", BF16), B, Cin, HW, C0)
+    return out16
+
+
+def depth_to_space2_bf16(x16, B, H, W, C):
+    """[B*H*W, 4C] bf16 with columns (dy, dx, c) -> [B*2H*2W, C] bf16."""
+    out = torch.empty(B * 4 * H * W, C, device=x16.device, dtype=BF16)
+    _call("ldm_depth_to_space2_bf16", _dev(x16, "x", BF16), _dev(out, "out", BF16), B, H, W, C)
+    return out
+
+
+def rgb_head_bf16(x16, w, bias, prev, out, B, H, W, C):
+    _call("ldm_rgb_head_bf16", _dev(x16, "x", BF16), _dev(w, "w"), _dev(bias, "bias"), _opt(prev, "prev"), _dev(out, "out"), B, H, W, C)
+    return out
+
+
+def up2_add(coarse, skip, out, B, H, W, C):
+    _call("ldm_up2_add_f32", _dev(coarse, "coarse"), _opt(skip, "skip"), _dev(out, "out"), B, H, W, C)
+    return out
+
+
+def avgpool2_bf16(x, out16, B, H, W, C):
+    _call("ldm_avgpool2_bf16", _dev(x, "x"), _dev(out16, "out", BF16), B, H, W, C)
+    return out16

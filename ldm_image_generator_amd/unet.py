@@ -221,6 +221,12 @@ class UNet(nn.Module):
         self.hoist_budget_bytes = 16 << 30 # ... unless those tables would need more workspace than this (2.3 GB at 50 steps, 32x32 latents)
         self._films_key = None             # identity of the tables currently in the workspace (None: not valid)
         self._slot_table = None
+        # reduced-precision sampling (ddpm.py:52,75: the reference samples under 16-bit autocast on a GPU).  Opt-in: None (default) keeps
+        # every forward exact fp32 whatever `use_autocast` says; torch.bfloat16 (autocast.set_autocast_dtype) makes
+        # DDPM.sample(use_autocast=True) run its UNet forwards with bf16 GEMM operands (fp32 accumulate, fp32 residual stream)
+        self.autocast_dtype = None
+        self._autocast_now = False         # set by DDPM.sample for the duration of an autocast loop
+        self._plan16 = None
 
     def _level_blocks(self, i):
         n = len(self.encoder_stages)
@@ -328,12 +334,67 @@ class UNet(nn.Module):
         self._plan = (key, plan, keep, order, captured)
         return plan
 
+    def _gemm_weights16(self, order):
+        """(parameter, [rows, cols] view) of every weight the bf16 forward reads, block by block."""
+        out = []
+        for blk in order:
+            out.append(("conv", blk, blk._conv_weight()))
+            for k, r in enumerate([blk.ffn.general] + list(blk.ffn.experts)):
+                out += [(("a", k), blk, w2d(r.a)), (("b", k), blk, w2d(r.b)), (("c", k), blk, w2d(r.c))]
+            if blk.attention_flag:
+                att = blk.self_attention.attention
+                out += [("in", blk, att.in_proj_weight.detach()), ("out", blk, att.out_proj.weight.detach())]
+        return out
+
+    def _native_plan16(self, dev, check=True):
+        """struct ldm_unet_plan_bf16: bf16 copies of the GEMM weights (one flat buffer), re-cast when any weight changed.
+        ``check=False`` (later steps of one denoise loop: weights cannot have moved since its first step) skips the version scan."""
+        import ctypes
+        from ._lib import UNetBlock16Desc, UNetPlan16Desc
+        if not check and self._plan16 is not None:
+            return self._plan16[1]
+        self._native_plan(dev)
+        order = self._plan[3]
+        srcs = [p for l in (list(self.encoder_stages) + list(self.decoder_stages)) for blk in l.stage.blocks for p in blk.parameters()]
+        key = (self._plan[0], sum(p._version for p in srcs), tuple(blk.conv.weight.data_ptr() for blk in order))
+        if self._plan16 is not None and self._plan16[0] == key:
+            return self._plan16[1]
+        for c in self.channels:
+            if c % 64:
+                raise NotImplementedError("bf16 sampling needs every stage width to be a multiple of 64 (got %r)" % (self.channels,))
+        items = self._gemm_weights16(order)
+        total = sum(w.numel() for _, _, w in items)
+        buf = torch.empty(total, device=dev, dtype=torch.bfloat16)
+        blocks = (UNetBlock16Desc * len(order))()
+        index = {blk: i for i, blk in enumerate(order)}
+        off = 0
+        for name, blk, w in items:
+            n = w.numel()
+            dst = buf[off:off + n]
+            ops.cast_bf16(w.contiguous().reshape(-1), dst)
+            off += n
+            bd = blocks[index[blk]]
+            if name == "conv":
+                bd.conv_w = dst.data_ptr()
+            elif name == "in":
+                bd.in_w = dst.data_ptr()
+            elif name == "out":
+                bd.out_w = dst.data_ptr()
+            else:
+                getattr(bd, name[0] + "_w")[name[1]] = dst.data_ptr()
+        plan16 = UNetPlan16Desc()
+        plan16.nblocks = len(order)
+        plan16.blocks = ctypes.cast(blocks, ctypes.POINTER(UNetBlock16Desc))
+        self._plan16 = (key, plan16, (buf, blocks))
+        return plan16
+
     def invalidate_caches(self):
         """Drop every derived copy of the weights (native plan, pointer tables, packed grouped-conv filters).  Needed only after
         writing weights in place through ``.data`` (p.data.copy_(), EMA swaps, clipping), which bumps no version counter; updates
         through the Parameter itself (optimizer steps, load_state_dict, p.copy_ under no_grad) are tracked automatically."""
         weights.bump()                     # every version-keyed copy (transposed / bf16 weights of the training step too)
         self._plan = None
+        self._plan16 = None
         self._tables = {}
         for stack in list(self.encoder_stages) + list(self.decoder_stages):
             for blk in stack.stage.blocks:
@@ -341,6 +402,7 @@ class UNet(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._plan = None                  # parameters are about to be replaced (.to / .cuda / .float)
+        self._plan16 = None
         self._tables = {}
         return super()._apply(fn, *args, **kwargs)
 
@@ -385,10 +447,17 @@ class UNet(nn.Module):
         ready = int(key is not None and key == self._films_key)
         out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
         x = x.contiguous().float()
-        _lib.check(lib.ldm_unet_forward_ex_f32(ctypes.byref(plan), x.data_ptr(), t_unique.data_ptr(), nt,
-                                               None if slot is None else slot.data_ptr(), dec, b, h, w,
-                                               self._workspace.data_ptr(), need, out.data_ptr(), ready,
-                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_unet_forward_ex_f32")
+        if self._autocast_now and self.autocast_dtype is torch.bfloat16:
+            plan16 = self._native_plan16(dev, check=not ready)
+            _lib.check(lib.ldm_unet_forward_bf16(ctypes.byref(plan), ctypes.byref(plan16), x.data_ptr(), t_unique.data_ptr(), nt,
+                                                 None if slot is None else slot.data_ptr(), dec, b, h, w,
+                                                 self._workspace.data_ptr(), need, out.data_ptr(), ready,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_unet_forward_bf16")
+        else:
+            _lib.check(lib.ldm_unet_forward_ex_f32(ctypes.byref(plan), x.data_ptr(), t_unique.data_ptr(), nt,
+                                                   None if slot is None else slot.data_ptr(), dec, b, h, w,
+                                                   self._workspace.data_ptr(), need, out.data_ptr(), ready,
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_unet_forward_ex_f32")
         self._films_key = key
         return out
 
@@ -406,7 +475,7 @@ class UNet(nn.Module):
             from ._lib import LdmHipUnavailable
             raise LdmHipUnavailable("x must be a GPU tensor: the HIP path is the only implementation (no CPU fallback)")
         ctx = TimeContext(time, b, dev, uniform=self._uniform_time)
-        if self.native_forward:
+        if self.native_forward or self._autocast_now:          # the bf16 mode exists in the native executor only
             return self._forward_native(x, ctx)
         # Python-RNG decisions of all 36 blocks in execution order (identical draw order to the
         # reference, which draws them lazily inside each block: nothing else touches `random`).

@@ -43,6 +43,22 @@ def _pack_convt(w):    # ConvTranspose2d [Cin, Cout, 2, 2] -> [(dy, dx, co)][ci]
     return w.permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0])
 
 
+def _bf16(fn):
+    """A weight re-layout followed by one RNE rounding to bf16 (ldm_cast_bf16), for _PackedWeight."""
+    return lambda w: ops.cast_bf16(fn(w).contiguous())
+
+
+def conv3x3_rows16(rows16, shape, conv, packed16, slope=0.01, addend16=None):
+    """conv3x3_rows in the bf16 decode mode: bf16 rows in, bf16 rows out, fp32 accumulate; the skip is added in fp32 before the
+    one rounding of the result."""
+    b, h, w = shape
+    cin, cout = conv.weight.shape[1], conv.weight.shape[0]
+    out = torch.empty(rows16.shape[0], cout, device=rows16.device, dtype=torch.bfloat16)
+    ops.gemm_bf16(rows16, rows16.shape[0], cout, 9 * cin, [packed16.get(conv.weight)], out, ldw=9 * cin, biases=[conv.bias.detach()],
+                  act=ops.ACT_LRELU, slope=slope, addend=addend16, a_mode=ops.A_CONV3X3, conv_hw=(h, w), cin=cin)
+    return out
+
+
 def conv3x3_rows(rows, shape, conv, packed, slope=0.01, addend=None):
     """lrelu(conv3x3(x) + bias) (+ addend) on channels-last rows."""
     b, h, w = shape
@@ -63,8 +79,13 @@ class ResBlock(nn.Module):
         self.c2 = nn.Conv2d(channels, channels, 3, 1, 1)
         self._p1 = _PackedWeight(_pack3x3)
         self._p2 = _PackedWeight(_pack3x3)
+        self._p1h = _PackedWeight(_bf16(_pack3x3))
+        self._p2h = _PackedWeight(_bf16(_pack3x3))
 
     def forward_rows(self, rows, shape):
+        if rows.dtype == torch.bfloat16:                      # bf16 decode mode (autocast.set_compute_dtype)
+            y = conv3x3_rows16(rows, shape, self.c1, self._p1h)
+            return conv3x3_rows16(y, shape, self.c2, self._p2h, addend16=rows)
         y = conv3x3_rows(rows, shape, self.c1, self._p1)
         return conv3x3_rows(y, shape, self.c2, self._p2, addend=rows)
 
@@ -146,7 +167,8 @@ class DecoderStack(nn.Module):
             rows = blk.forward_rows(rows, shape)
         b, h, w = shape
         rgb = torch.empty(b, 3, h, w, device=rows.device, dtype=torch.float32)
-        ops.rgb_head(rows, w2d(self.to_rgb), self.to_rgb.bias.detach(), prev_rgb, rgb, b, h, w, rows.shape[1])
+        head = ops.rgb_head_bf16 if rows.dtype == torch.bfloat16 else ops.rgb_head
+        head(rows, w2d(self.to_rgb), self.to_rgb.bias.detach(), prev_rgb, rgb, b, h, w, rows.shape[1])
         return rows, rgb
 
     def forward(self, x):
@@ -168,6 +190,12 @@ class Decoder(nn.Module):
             else:
                 self.upsamples.append(nn.ConvTranspose2d(channels[i - 1], c, 2, 2, 0))
         self._up_packed = [_PackedWeight(_pack_convt) for _ in channels]
+        self._up_packed16 = [_PackedWeight(_bf16(_pack_convt)) for _ in channels]
+        self._up_bias4 = [_PackedWeight(lambda b: b.repeat(4)) for _ in channels]       # bias per (dy, dx, co) column of the 2x2 GEMM
+        # None: exact fp32 (default).  torch.bfloat16 (autocast.set_compute_dtype): activations travel as bf16 rows, every conv
+        # accumulates in fp32 on v_mfma_f32_32x32x16_bf16, RGB planes stay fp32.  An extension beyond the reference, which decodes
+        # in fp32 outside its autocast region (sample_ldm.py:73-74).
+        self.compute_dtype = None
 
     def forward(self, x):
         """vae.py:122-132: z [B, latent, h, w] -> RGB [B, 3, 8h, 8w] (NCHW)."""
@@ -178,6 +206,8 @@ class Decoder(nn.Module):
         b, cz, h, w = x.shape
         dev = x.device
         c0 = self.input_layer.weight.shape[0]
+        if self.compute_dtype is torch.bfloat16:
+            return self._forward_bf16(x)
         rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.float32)
         ops.stem_nchw(x.contiguous().float(), w2d(self.input_layer), self.input_layer.bias.detach(), rows, b, cz, h * w, c0)
         rgb = None
@@ -191,6 +221,34 @@ class Decoder(nn.Module):
                 h, w = 2 * h, 2 * w
             rows, rgb = stage.forward_rows(rows, (b, h, w), rgb)
         return rgb
+
+
+def _decoder_forward_bf16(self, x):
+    """Decoder.forward with bf16 activations (vae.py:122-132 under a 16-bit compute type): the input layer writes bf16 rows, every
+    dense 3x3 is a bf16 implicit GEMM (fp32 accumulate, bias + leaky_relu + skip in fp32, one rounding), ConvTranspose2d(2, 2) is
+    a bf16 GEMM to (dy, dx, co) columns followed by the depth-to-space pass, to_rgb + bilinear accumulation stay fp32 planes."""
+    b, cz, h, w = x.shape
+    dev = x.device
+    chans = [self.input_layer.weight.shape[0]] + [up.weight.shape[1] for up in self.upsamples if not isinstance(up, nn.Identity)]
+    if any(c % 64 for c in chans):
+        raise NotImplementedError("bf16 decode needs every stage width to be a multiple of 64 (got %r)" % (chans,))
+    c0 = chans[0]
+    rows = torch.empty(b * h * w, c0, device=dev, dtype=torch.bfloat16)
+    ops.stem_nchw_bf16(x.contiguous().float(), w2d(self.input_layer), self.input_layer.bias.detach(), rows, b, cz, h * w, c0)
+    rgb = None
+    for i, (up, stage) in enumerate(zip(self.upsamples, self.stages)):
+        if not isinstance(up, nn.Identity):
+            cin, cout = up.weight.shape[0], up.weight.shape[1]
+            quad = torch.empty(b * h * w, 4 * cout, device=dev, dtype=torch.bfloat16)
+            ops.gemm_bf16(rows, b * h * w, 4 * cout, cin, [self._up_packed16[i].get(up.weight)], quad, biases=[self._up_bias4[i].get(up.bias)])
+            rows = ops.depth_to_space2_bf16(quad, b, h, w, cout)
+            del quad
+            h, w = 2 * h, 2 * w
+        rows, rgb = stage.forward_rows(rows, (b, h, w), rgb)
+    return rgb
+
+
+Decoder._forward_bf16 = _decoder_forward_bf16
 
 
 class _VQLossFunction(torch.autograd.Function):
