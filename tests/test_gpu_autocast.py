@@ -4,9 +4,9 @@ Kernel level: exact-input tests -- operands are bf16 values, the reference is ev
 only admissible difference is the final rounding position (<= 1 bf16 ulp on a few elements: rel-L2 <= 4e-3, the bf16 rounding
 noise level 2^-9 / sqrt(3)).  Bit-identity where two kernels run the same MFMA order (ring vs stream gate).
 
-Model level: the bf16 mode against the REFERENCE's fp32 goldens (tests/golden/*.npz).  Stated tolerance (about twice what was
-measured on MI355X, printed by the tests): UNet forward rel-L2 <= 1.5e-2; 3-step latents <= 1.5e-2, 50-step latents <= 3e-2;
-decoded image <= 1e-2.  The default path stays exact fp32: `use_autocast` alone changes nothing.
+Model level: the bf16 mode against the REFERENCE's fp32 goldens (tests/golden/*.npz).  Stated tolerance = about twice what was
+measured on MI355X (printed by the tests; measured: UNet forward 1.3e-3, 3-step latents 1.1e-3, 50-step latents 4.0e-4, decoded
+image 2.5e-3 ... 2.8e-3): UNet forward rel-L2 <= 3e-3; 3-step latents <= 2.5e-3, 50-step latents <= 1.5e-3; decoded image <= 6e-3.  The default path stays exact fp32: `use_autocast` alone changes nothing.
 """
 import random
 
@@ -170,7 +170,7 @@ def test_bf16_sampling_small_net_vs_fp32_path(gpu_device):
         assert torch.equal(off, ref)                              # opted in, but use_autocast=False: exact fp32
         err = rel_l2(got.cpu(), ref.cpu())
         print("bf16 sampling, small net, %s mode, 5 steps: rel-L2 %.3e vs the fp32 path" % (mode, err))
-        assert err < 3e-2
+        assert err < 1.5e-3
 
 
 @pytest.fixture(scope="module")
@@ -195,7 +195,7 @@ def test_bf16_unet_forward_full_size_vs_reference(full_unet):
                 net._autocast_now = False
                 err = rel_l2(y.cpu(), T(g[key]))
                 print("bf16 UNet forward, full size, %s: rel-L2 %.3e vs the reference's fp32 output" % (mode, err))
-                assert err < 1.5e-2
+                assert err < 3e-3
     finally:
         net._autocast_now = False
         autocast.set_autocast_dtype(net, None)
@@ -218,7 +218,7 @@ def test_bf16_ddim_sample_full_size_vs_reference(full_unet):
     finally:
         autocast.set_autocast_dtype(net, None)
     print("bf16 DDIM sampling, full size: 50 steps (train mode) rel-L2 %.3e, 3 steps (eval) %.3e vs the reference's fp32 latents" % (e50, e3))
-    assert e3 < 1.5e-2 and e50 < 3e-2
+    assert e3 < 2.5e-3 and e50 < 1.5e-3
 
 
 def test_bf16_decoder_full_size_vs_reference(gpu_device):
@@ -232,7 +232,7 @@ def test_bf16_decoder_full_size_vs_reference(gpu_device):
     e_sub = rel_l2(y[:, :, ::4, ::4], T(g["y_sub"]))
     e_rows = rel_l2(y[:, :, 100:104, :], T(g["y_rows"]))
     print("bf16 decode, full size: rel-L2 %.3e (subsampled image), %.3e (rows 100-103) vs the reference's fp32 image" % (e_sub, e_rows))
-    assert e_sub < 1e-2 and e_rows < 1e-2
+    assert e_sub < 6e-3 and e_rows < 6e-3
     autocast.set_compute_dtype(dec, None)
     with torch.no_grad():
         y32 = dec(T(g["z"]).cuda()).cpu()
@@ -250,4 +250,4 @@ def test_bf16_decoder_tiny_vs_fp32_path(gpu_device):
         got = dec(z)
     err = rel_l2(got.cpu(), ref.cpu())
     print("bf16 decode, tiny net: rel-L2 %.3e vs the fp32 path" % err)
-    assert err < 1e-2
+    assert err < 6e-3
