@@ -115,6 +115,9 @@ typedef struct ldm_gemm_desc {
 int         ldm_version(void);
 const char *ldm_last_error(void);
 int         ldm_device_ok(void);          /* 1 if device 0 is gfx950 */
+/* The library keeps one grow-only device scratch per (device, stream) for the fixed-order partial sums of its reductions (loss scalars,
+ * bias / column sums, stem / head weight gradients): no float atomics, results are bit-reproducible from run to run.  Frees them all. */
+int         ldm_scratch_release(void);
 
 int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
 /* schedule used by ldm_gemm_f32: 0 = one tile per workgroup, 1 = persistent LDS-DMA stream (default); both use
@@ -141,6 +144,8 @@ int ldm_prof_read(long long *launches, double *ms, double *flops);     /* all cl
  * 5 grouped conv with bf16 operands; cls < 0 = all.  Does not clear (call ldm_prof_read last). */
 int ldm_prof_read_class(int cls, long long *launches, double *ms, double *flops);
 int ldm_prof_read_bytes(int cls, double *bytes);    /* summed algorithmic HBM bytes of the class's launches (operands once) */
+/* every record in launch order: out[4 i ..] = (class, kernel ms, algorithmic FLOPs, algorithmic bytes); returns the count (<= max_records) */
+long long ldm_prof_dump(double *out, long long max_records);
 
 /* modules.py:23-25 (ChannelNorm, unbiased var, eps inside sqrt) fused with the
  * FiLM of unet.py:22.  film is [nslot, HW, 2C] (mul | bias); slot[b] selects the
@@ -394,9 +399,11 @@ int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, i
  * exact fp32.  GEMM operands are bf16 with fp32 accumulation; the UNet's residual stream, FiLM tables, attention core
  * and the DDIM update stay fp32; the VAE decoder keeps its activations as bf16 rows and emits fp32 RGB planes.
  * ------------------------------------------------------------------------------------------------ */
-/* ldm_window_attention_f32 with the fp32 QKV of a bf16 in-projection: the float "mask" source of shifted windows is the bf16
- * normalised input xf_bf16 [B,H,W,C] (NULL allowed when shift == 0) and the context leaves as bf16 rows [B,H,W,C].  ws*ws <= 48. */
-int ldm_window_attention_bf16io(const float *qkv, const float *in_proj_bias, const void *xf_bf16, void *out_bf16,
+/* ldm_window_attention_f32 behind a bf16 in-projection: qkv [B,H,W,3C] is fp32 (qkv_is_bf16 == 0) or bf16 (!= 0: widened exactly
+ * on load, zero-padded tokens take the bias rounded to bf16); the float "mask" source of shifted windows is the bf16 normalised
+ * input xf_bf16 [B,H,W,C] (NULL allowed when shift == 0); the context leaves as bf16 rows [B,H,W,C].  The attention arithmetic
+ * (scores, softmax, P.V) is fp32.  ws*ws <= 48. */
+int ldm_window_attention_bf16io(const void *qkv, int qkv_is_bf16, const float *in_proj_bias, const void *xf_bf16, void *out_bf16,
                                 int B, int H, int W, int C, int ws, int shift, void *stream);
 /* ldm_stem_nchw_f32 with bf16 rows out (VAE Decoder.input_layer, vae.py:112,123) */
 int ldm_stem_nchw_bf16(const float *x, const float *w, const float *bias, void *out_bf16, int B, int Cin, int HW, int C0, void *stream);

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ldm_version": (_I, []),
     "ldm_last_error": (ctypes.c_char_p, []),
     "ldm_device_ok": (_I, []),
+    "ldm_scratch_release": (_I, []),
     "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "ldm_gemm_variant": (_I, [_I]),
     "ldm_gemm_wide_epilogue": (_I, [_I]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "ldm_prof_enable": (_I, [_I]),
     "ldm_prof_read": (_I, [ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ldm_prof_read_bytes": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),
+    "ldm_prof_dump": (_L, [ctypes.POINTER(ctypes.c_double), _L]),
     "ldm_prof_read_class": (_I, [_I, ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ldm_channelnorm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_film_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -172,7 +174,7 @@ SIGNATURES = {
     "ldm_film_hidden_bwd_chunks": (_I, [_I, _I, _I]),
     "ldm_film_hidden_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     # bf16 sampling / decode
-    "ldm_window_attention_bf16io": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_window_attention_bf16io": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ldm_stem_nchw_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_depth_to_space2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_rgb_head_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")           # git-ignored and gpurun-ignored: only the .so travels
 LIB = os.path.join(HERE, "libldm_hip.so")
 SOURCES = ["gemm.hip", "gemm_stream.hip", "gconv.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "backward.hip", "unet_exec.cpp", "prof.cpp", "gemm_bf16.hip", "gemm_ring.hip", "bf16_ops.hip", "gconv_bf16.hip", "gconv_wgrad_bf16.hip", "vq.hip", "vae_bwd.hip",
-           "conv3x3_bf16.hip", "infer_bf16.hip", "batched_ops.hip"]
+           "infer_bf16.hip", "scratch.cpp", "batched_ops.hip"]
 # -ffp-contract=off: products and sums round separately unless the source says fmaf(); several
 # kernels reproduce the reference's op-by-op fp32 rounding (ddim_update, qsample, FiLM, uint8).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]

@@ -19,6 +19,8 @@ struct AttnP {
     // windows (attention.py:40) is read from the bf16 copy of the normalised input; the attention arithmetic itself stays fp32
     unsigned short *out16;
     const unsigned short *xf16;
+    const unsigned short *qkv16;   // the packed in-projection as bf16 rows (then `qkv` is NULL): q, k, v are widened exactly on load; padded
+                                   // tokens take the bias rounded to bf16 -- what the bf16 projection of a zero row would have stored
     int B, H, W, C, ws, shift;
     int Hp, Wp, nwh, nww, heads, L;
     int global;     // H<=ws && W<=ws: one window of H*W tokens, no mask
@@ -161,6 +163,35 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const AttnP p)
 }
 
 // ---- MFMA version (L <= 48 tokens: every window the reference ever builds) -----------------------------------------
+// eight consecutive values of the packed in-projection (element offset `off`) or, for a zero-padded token, of the bias (offset `boff`)
+__device__ __forceinline__ void load8(const AttnP &p, bool ok, long long off, int boff, f32x4 &lo, f32x4 &hi)
+{
+    if (p.qkv16) {
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        if (ok) {
+            const u32x4v w = *(const u32x4v *)(p.qkv16 + off);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                lo[2 * e] = __uint_as_float(w[e] << 16);
+                lo[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+                hi[2 * e] = __uint_as_float(w[2 + e] << 16);
+                hi[2 * e + 1] = __uint_as_float(w[2 + e] & 0xFFFF0000u);
+            }
+        } else {
+            const f32x4 b0 = *(const f32x4 *)(p.bias + boff), b1 = *(const f32x4 *)(p.bias + boff + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = (float)(__bf16)b0[e];
+                hi[e] = (float)(__bf16)b1[e];
+            }
+        }
+    } else {
+        const float *src = ok ? p.qkv + off : p.bias + boff;
+        lo = *(const f32x4 *)src;
+        hi = *(const f32x4 *)(src + 4);
+    }
+}
+
 // One wave per (sample, window, head); v_mfma_f32_16x16x4_f32 (exact fp32) for both products.
 //   S^T = K Q^T   tiles [key tile][query tile]: the A operand is K, the B operand is Q; a lane (c = lane & 15,
 //                 g = lane >> 4) reads row c of the tile straight from global memory, dims [8g, 8g + 8) (the contraction
@@ -202,27 +233,27 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const AttnP 
             int sy = 0, sx = 0, py, px;
             const bool ok = j < L && token_src(p, wr, wc, j, sy, sx, py, px);
             // zero-padded token: the projection of 0 is the bias (attention.py:27-28); tokens past L only need finite values
-            const float *row = ok ? p.qkv + (img + (long long)sy * p.W + sx) * 3 * C + head * 32 : p.bias + head * 32;
+            const long long roff = (img + (long long)sy * p.W + sx) * 3 * C + head * 32;
             qok[t] = ok;
             orow[t] = (img + (long long)sy * p.W + sx) * C + head * 32;
+            f32x4 qv[2];
+            load8(p, ok, roff + 8 * g, head * 32 + 8 * g, qv[0], qv[1]);
+            load8(p, ok, roff + C + 8 * g, C + head * 32 + 8 * g, kf[t][0], kf[t][1]);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const f32x4 qv = *(const f32x4 *)(row + 8 * g + 4 * u);
-                kf[t][u] = *(const f32x4 *)(row + C + 8 * g + 4 * u);
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qf[t][u][e] = __fmul_rn(qv[e], scale);
-            }
+                for (int e = 0; e < 4; ++e) qf[t][u][e] = __fmul_rn(qv[u][e], scale);
         }
-        for (int idx = lane; idx < LT * 8; idx += 64) {
-            const int j = idx >> 3, ch = (idx & 7) * 4;
-            int sy, sx, py, px;
-            f32x4 vv{0.f, 0.f, 0.f, 0.f};
+        for (int idx = lane; idx < LT * 4; idx += 64) {
+            const int j = idx >> 2, ch = (idx & 3) * 8;
+            int sy = 0, sx = 0, py, px;
+            f32x4 v0{0.f, 0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f, 0.f};
             if (j < L) {
                 const bool ok = token_src(p, wr, wc, j, sy, sx, py, px);
-                vv = ok ? *(const f32x4 *)(p.qkv + (img + (long long)sy * p.W + sx) * 3 * C + 2 * C + head * 32 + ch)
-                        : *(const f32x4 *)(p.bias + 2 * C + head * 32 + ch);
+                load8(p, ok, (img + (long long)sy * p.W + sx) * 3 * C + 2 * C + head * 32 + ch, 2 * C + head * 32 + ch, v0, v1);
             }
-            *(f32x4 *)(Vs + j * RS + ch) = vv;
+            *(f32x4 *)(Vs + j * RS + ch) = v0;
+            *(f32x4 *)(Vs + j * RS + ch + 4) = v1;
         }
         if (lane < LT) {
             float kb = -INFINITY;
@@ -341,7 +372,7 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const AttnP 
 }  // namespace
 
 static int window_attention_impl(const float *qkv, const float *in_proj_bias, const float *xf, const void *xf16, float *out, void *out16, int B, int H,
-                                 int W, int C, int ws, int shift, void *stream);
+                                 int W, int C, int ws, int shift, void *stream, bool qkv16 = false);
 
 extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_bias, const float *xf, float *out, int B, int H,
                                         int W, int C, int ws, int shift, void *stream)
@@ -349,15 +380,15 @@ extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_b
     return window_attention_impl(qkv, in_proj_bias, xf, nullptr, out, nullptr, B, H, W, C, ws, shift, stream);
 }
 
-extern "C" int ldm_window_attention_bf16io(const float *qkv, const float *in_proj_bias, const void *xf_bf16, void *out_bf16, int B, int H,
+extern "C" int ldm_window_attention_bf16io(const void *qkv, int qkv_is_bf16, const float *in_proj_bias, const void *xf_bf16, void *out_bf16, int B, int H,
                                            int W, int C, int ws, int shift, void *stream)
 {
     LDM_REQUIRE(out_bf16 && (((size_t)out_bf16) & 7) == 0, "ldm_window_attention_bf16io: null / unaligned output");
-    return window_attention_impl(qkv, in_proj_bias, nullptr, xf_bf16, nullptr, out_bf16, B, H, W, C, ws, shift, stream);
+    return window_attention_impl((const float *)qkv, in_proj_bias, nullptr, xf_bf16, nullptr, out_bf16, B, H, W, C, ws, shift, stream, qkv_is_bf16 != 0);
 }
 
 static int window_attention_impl(const float *qkv, const float *in_proj_bias, const float *xf, const void *xf16, float *out, void *out16, int B, int H,
-                                 int W, int C, int ws, int shift, void *stream)
+                                 int W, int C, int ws, int shift, void *stream, bool qkv16)
 {
     LDM_REQUIRE(qkv && in_proj_bias && (out || out16), "ldm_window_attention_f32: null pointer");
     LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0, "ldm_window_attention_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
@@ -365,7 +396,8 @@ static int window_attention_impl(const float *qkv, const float *in_proj_bias, co
     LDM_REQUIRE(shift >= 0 && shift < ws, "ldm_window_attention_f32: shift=%d", shift);
     LDM_REQUIRE(ldm_aligned16(qkv) && ldm_aligned16(in_proj_bias) && (!out || ldm_aligned16(out)), "ldm_window_attention_f32: unaligned pointer");
     AttnP p{};
-    p.qkv = qkv; p.bias = in_proj_bias; p.xf = xf; p.out = out;
+    p.qkv = qkv16 ? nullptr : qkv; p.qkv16 = qkv16 ? (const unsigned short *)qkv : nullptr;
+    p.bias = in_proj_bias; p.xf = xf; p.out = out;
     p.out16 = (unsigned short *)out16; p.xf16 = (const unsigned short *)xf16;
     p.B = B; p.H = H; p.W = W; p.C = C; p.ws = ws; p.shift = shift;
     p.heads = C / 32;
@@ -388,6 +420,7 @@ static int window_attention_impl(const float *qkv, const float *in_proj_bias, co
     } else if (p.L <= 48) {
         hipLaunchKernelGGL(window_attention_mfma_kernel<3>, dim3(blocks), dim3(256), 4ull * (48 * 36 + 48) * sizeof(float), st, p);
     } else {
+        LDM_REQUIRE(!out16 && !xf16 && !qkv16, "ldm_window_attention_bf16io: windows of more than 48 tokens have no bf16 I/O kernel");
         const size_t smem = 4ull * (2 * 64 * 32 + 64) * sizeof(float);
         static LdmLdsOptIn opt_in;
         (void)opt_in((const void *)window_attention_kernel<64>, smem);

@@ -68,7 +68,8 @@ __global__ void add_kernel(f32x4 *y, const f32x4 *x, long long n4)
     y[i] = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
 }
 
-// column sums of a row-major [M, N] matrix (bias gradients): 512-row slabs, one atomic per column per slab
+// column sums of a row-major [M, N] matrix (bias gradients): slab blockIdx.y writes ITS sums to plane blockIdx.y of `out` ([slabs][N]);
+// the planes are added in slab order by reduce_planes (no float atomics: bit-reproducible)
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long long M, int N, int slab)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     const long long m1 = m0 + slab < M ? m0 + slab : M;
     float s = 0.f;
     for (long long m = m0; m < m1; ++m) s += x[m * N + n];
-    atomicAdd(out + n, s);
+    out[(long long)blockIdx.y * N + n] = s;
 }
 
 __global__ void reduce_partials_kernel(const float *__restrict__ parts, float *__restrict__ out, int S, long long n)
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float *__restrict__
             const int pix = (int)(m - b * HW);
             s = fmaf(dy[m * C0 + n], x[(b * Cin + ci) * HW + pix], s);
         }
-        atomicAdd(dw + idx, s);
+        dw[(long long)blockIdx.x * C0 * Cin + idx] = s;                  // plane blockIdx.x of the partial sums
     }
 }
 
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kRowsNT) void stem_bwd_rows_kernel(const float *__r
         const int nn = i / Cin, c = i - nn * Cin;
         float sum = 0.f;
         for (int g = 0; g < nrg; ++g) sum += xs[(g * C0 + nn) * CP + c];
-        atomicAdd(dw + i, sum);
+        dw[(long long)blockIdx.x * C0 * Cin + i] = sum;                  // plane blockIdx.x of the partial sums
     }
 }
 
@@ -397,12 +398,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
             const long long m = m0 + pl;
             if (m < M) s = fmaf(x[m * C0 + c], gt[pl * 17 + co], s);
         }
-        atomicAdd(dw + i, s);
+        dw[(long long)blockIdx.x * (C0 * Cin + Cin) + i] = s;            // plane blockIdx.x: [C0 * Cin weight sums | Cin bias sums]
     }
     if (t < Cin) {
         float s = 0.f;
         for (int pl = 0; pl < 64; ++pl) s += gt[pl * 17 + t];
-        atomicAdd(db + t, s);
+        dw[(long long)blockIdx.x * (C0 * Cin + Cin) + C0 * Cin + t] = s;
     }
 }
 
@@ -478,14 +479,14 @@ __global__ __launch_bounds__(kRowsNT) void head_bwd_rows_kernel(const float *__r
         const int cc = i / Cin, co = i - cc * Cin;
         float sum = 0.f;
         for (int g2 = 0; g2 < nrg; ++g2) sum += sm[(g2 * C0 + cc) * CP + co];
-        atomicAdd(dw + i, sum);
+        dw[(long long)blockIdx.x * (C0 * Cin + Cin) + i] = sum;          // plane blockIdx.x: [C0 * Cin weight sums | Cin bias sums]
     }
-    if (t < Cin) atomicAdd(db + t, accb);
+    if (t < Cin) dw[(long long)blockIdx.x * (C0 * Cin + Cin) + C0 * Cin + t] = accb;
 }
 
 // ---- L1 loss (ddpm.py:47 with nn.L1Loss) ----------------------------------------------------------
-__global__ __launch_bounds__(256) void l1_loss_kernel(const float *__restrict__ p, const float *__restrict__ q, long long n, float inv_n,
-                                                      float *__restrict__ loss)
+// per-block sums to parts[blockIdx.x]; l1_loss_finish_kernel adds them in a fixed order (no float atomics: the loss is bit-reproducible)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float *__restrict__ p, const float *__restrict__ q, long long n, float *__restrict__ parts)
 {
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += fabsf(p[i] - q[i]);
@@ -493,7 +494,21 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float *__restrict__ 
     __shared__ float ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n);
+    if (threadIdx.x == 0) parts[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_loss_finish_kernel(const float *__restrict__ parts, int nparts, float inv_n, float *__restrict__ loss)
+{
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += parts[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = sh[0] * inv_n;
 }
 
 __global__ void l1_loss_bwd_kernel(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ gscale, float inv_n,
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(256) void transpose_colsum_kernel(const float *__re
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += part[k][tx];
-        atomicAdd(csum + c0 + tx, t);
+        csum[(long long)blockIdx.y * Cc + c0 + tx] = t;                   // plane blockIdx.y of the partial column sums
     }
 }
 
@@ -571,6 +586,8 @@ __global__ __launch_bounds__(256) void im2col3x3_t_kernel(const float *__restric
 struct AttnB {
     const float *qkv, *bias, *xf, *dctx;
     float *dqkv, *dbias_pad;
+    float *pad_parts;            // [total_waves][64]: every wave's (dk | dv) sums over ITS zero-padded tokens (zeros if it has none); added per
+                                 // head in wave order by attn_pad_finish_kernel -- no float atomics, the bias gradient is bit-reproducible
     int B, H, W, C, ws, shift;
     int Hp, Wp, nwh, nww, heads, L, global;
     long long total_waves;
@@ -772,7 +789,9 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
         const float *src = (lane < 32 ? Qs : dOs) + (lane & 31);
         float acc = 0.f;
         for (int r = 0; r < L; ++r) acc += src[r * RS];
-        atomicAdd(p.dbias_pad + (lane < 32 ? C : 2 * C) + head * 32 + (lane & 31), acc);
+        if (active) p.pad_parts[gw * 64 + lane] = acc;
+    } else if (active) {
+        p.pad_parts[gw * 64 + lane] = 0.f;
     }
 }
 
@@ -1058,10 +1077,33 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
             for (int e = 0; e < 4; ++e) {
                 const float sk = row_sum(pk[dt][e]), sv = row_sum(pv[dt][e]);
                 if (c == 0) {
-                    atomicAdd(p.dbias_pad + C + head * 32 + 16 * dt + 4 * g + e, sk);
-                    atomicAdd(p.dbias_pad + 2 * C + head * 32 + 16 * dt + 4 * g + e, sv);
+                    p.pad_parts[gw * 64 + 16 * dt + 4 * g + e] = sk;
+                    p.pad_parts[gw * 64 + 32 + 16 * dt + 4 * g + e] = sv;
                 }
             }
+    } else {
+        p.pad_parts[gw * 64 + lane] = 0.f;
+    }
+}
+
+// dbias_pad [3C]: zeros for the q third; for head h and j < 64 (k dims, then v dims) the sum over the (sample, window) pairs of
+// pad_parts[((pair) * heads + h) * 64 + j] -- sixteen contiguous ranges of pairs summed in order, then added in range order.
+__global__ __launch_bounds__(1024) void attn_pad_finish_kernel(const float *__restrict__ parts, long long pairs, int heads, int C, float *__restrict__ dbias_pad)
+{
+    __shared__ float sh[16][64];
+    const int h = blockIdx.x, j = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const long long per = (pairs + 15) / 16;
+    const long long w0 = r * per, w1 = w0 + per < pairs ? w0 + per : pairs;
+    float s = 0.f;
+    for (long long w = w0; w < w1; ++w) s += parts[(w * heads + h) * 64 + j];
+    sh[r][j] = s;
+    __syncthreads();
+    if (r == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][j];
+        dbias_pad[(j < 32 ? C : 2 * C) + h * 32 + (j & 31)] = t;
+        if (j < 32) dbias_pad[h * 32 + j] = 0.f;
     }
 }
 
@@ -1097,16 +1139,40 @@ extern "C" int ldm_add_f32(float *y, const float *x, long long n, void *stream)
     EW4_ENTRY("ldm_add_f32", add_kernel, (f32x4 *)y, (const f32x4 *)x, n / 4)
 }
 
+// out[i] = sum over planes s < S of parts[s * n + i] (+ out[i] when accumulate), in plane order: the fixed-order second step of every
+// reduction that used to end in float atomics.  `parts` may hold one spare plane behind the S used ones (accumulate copies out there).
+static int reduce_planes(float *parts, int S, long long n, float *out, int accumulate, hipStream_t st, const char *who)
+{
+    if (accumulate) {
+        if (hipMemcpyAsync(parts + (long long)S * n, out, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            ldm_set_error("%s: copy of the running sum failed", who);
+            return LDM_ELAUNCH;
+        }
+        ++S;
+    }
+    if (n % 4 == 0 && S >= 4 && ldm_aligned16(parts) && ldm_aligned16(out))
+        hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3(blocks_for(n / 4, 64)), dim3(256), 0, st, (const f32x4 *)parts, (f32x4 *)out, S, n / 4);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const float *)parts, out, S, n);
+    return LDM_OK;
+}
+
 extern "C" int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulate, void *stream)
 {
     LDM_REQUIRE(x && out && M > 0 && N > 0, "ldm_colsum_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
-        ldm_set_error("ldm_colsum_f32: memset failed");
-        return LDM_ELAUNCH;
+    // ~256 slabs whatever M is: enough blocks to fill the chip, few enough planes for the fixed-order sum
+    long long slab = (M + 255) / 256;
+    slab = slab < 64 ? 64 : slab;
+    const unsigned slabs = blocks_for(M, (int)slab);
+    if (slabs == 1 && !accumulate) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, st, x, out, M, N, (int)slab);
+    } else {
+        float *parts = (float *)ldm_scratch(st, (size_t)(slabs + 1) * N * sizeof(float));
+        if (!parts) return LDM_ELAUNCH;
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, slabs), dim3(256), 0, st, x, parts, M, N, (int)slab);
+        if (reduce_planes(parts, (int)slabs, N, out, accumulate, st, "ldm_colsum_f32") != LDM_OK) return LDM_ELAUNCH;
     }
-    const int slab = 512;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, blocks_for(M, slab)), dim3(256), 0, st, x, out, M, N, slab);
     LDM_CHECK_LAUNCH("ldm_colsum_f32");
     return LDM_OK;
 }
@@ -1116,8 +1182,11 @@ extern "C" int ldm_transpose_colsum_f32(const float *x, float *out, float *csum,
     LDM_REQUIRE(x && out && csum && R > 0 && Cc > 0, "ldm_transpose_colsum_f32: bad arguments");
     LDM_REQUIRE((R + 31) / 32 <= 0x7fffffffLL, "ldm_transpose_colsum_f32: too many rows");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(csum, 0, (size_t)Cc * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_transpose_colsum_f32: memset failed"); return LDM_ELAUNCH; }
-    hipLaunchKernelGGL(transpose_colsum_kernel, dim3((Cc + 31) / 32, (unsigned)((R + 31) / 32)), dim3(256), 0, st, x, out, csum, R, Cc);
+    const unsigned rt = (unsigned)((R + 31) / 32);
+    float *parts = (float *)ldm_scratch(st, (size_t)rt * Cc * sizeof(float));
+    if (!parts) return LDM_ELAUNCH;
+    hipLaunchKernelGGL(transpose_colsum_kernel, dim3((Cc + 31) / 32, rt), dim3(256), 0, st, x, out, parts, R, Cc);
+    if (reduce_planes(parts, (int)rt, Cc, csum, 0, st, "ldm_transpose_colsum_f32") != LDM_OK) return LDM_ELAUNCH;
     LDM_CHECK_LAUNCH("ldm_transpose_colsum_f32");
     return LDM_OK;
 }
@@ -1185,19 +1254,27 @@ extern "C" int ldm_stem_bwd_f32(const float *x, const float *dy, float *dw, int 
 {
     LDM_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && HW > 0 && C0 > 0, "ldm_stem_bwd_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, (size_t)C0 * Cin * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_stem_bwd_f32: memset failed"); return LDM_ELAUNCH; }
     const long long M = (long long)B * HW;
+    const long long nw = (long long)C0 * Cin;
+    // every block writes its partial sums to ITS plane of the scratch; the planes are added in block order (bit-reproducible)
     if (C0 <= 256 && Cin <= 16) {
         long long per = ((M + 255) / 256 + kRowsNT - 1) / kRowsNT * kRowsNT;     // rows per block: ~256 blocks, whole 1024-row chunks
         if (per > 0x40000000LL) per = 0x40000000LL;
         const int slab = (int)per;
         const dim3 grid(blocks_for(M, slab));
-        if (Cin <= 4) hipLaunchKernelGGL(stem_bwd_rows_kernel<4>, grid, dim3(kRowsNT), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
-        else if (Cin <= 8) hipLaunchKernelGGL(stem_bwd_rows_kernel<8>, grid, dim3(kRowsNT), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
-        else hipLaunchKernelGGL(stem_bwd_rows_kernel<16>, grid, dim3(kRowsNT), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+        float *parts = (float *)ldm_scratch(st, (size_t)grid.x * nw * sizeof(float));
+        if (!parts) return LDM_ELAUNCH;
+        if (Cin <= 4) hipLaunchKernelGGL(stem_bwd_rows_kernel<4>, grid, dim3(kRowsNT), 0, st, x, dy, parts, M, Cin, HW, C0, slab);
+        else if (Cin <= 8) hipLaunchKernelGGL(stem_bwd_rows_kernel<8>, grid, dim3(kRowsNT), 0, st, x, dy, parts, M, Cin, HW, C0, slab);
+        else hipLaunchKernelGGL(stem_bwd_rows_kernel<16>, grid, dim3(kRowsNT), 0, st, x, dy, parts, M, Cin, HW, C0, slab);
+        if (reduce_planes(parts, (int)grid.x, nw, dw, 0, st, "ldm_stem_bwd_f32") != LDM_OK) return LDM_ELAUNCH;
     } else {
-        const int slab = 256;
-        hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for(M, slab)), dim3(256), 0, st, x, dy, dw, M, Cin, HW, C0, slab);
+        const int slab = (int)((M + 511) / 512 < 256 ? 256 : (M + 511) / 512);      // at most ~512 planes
+        const unsigned nb = blocks_for(M, slab);
+        float *parts = (float *)ldm_scratch(st, (size_t)nb * nw * sizeof(float));
+        if (!parts) return LDM_ELAUNCH;
+        hipLaunchKernelGGL(stem_bwd_kernel, dim3(nb), dim3(256), 0, st, x, dy, parts, M, Cin, HW, C0, slab);
+        if (reduce_planes(parts, (int)nb, nw, dw, 0, st, "ldm_stem_bwd_f32") != LDM_OK) return LDM_ELAUNCH;
     }
     LDM_CHECK_LAUNCH("ldm_stem_bwd_f32");
     return LDM_OK;
@@ -1209,19 +1286,32 @@ extern "C" int ldm_head_bwd_f32(const float *x, const float *w, const float *dou
     LDM_REQUIRE(x && w && dout && dx && dw && db, "ldm_head_bwd_f32: null pointer");
     LDM_REQUIRE(B > 0 && C0 > 0 && HW > 0 && Cin > 0 && Cin <= 16, "ldm_head_bwd_f32: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, (size_t)C0 * Cin * sizeof(float), st) != hipSuccess || hipMemsetAsync(db, 0, (size_t)Cin * sizeof(float), st) != hipSuccess) {
-        ldm_set_error("ldm_head_bwd_f32: memset failed");
-        return LDM_ELAUNCH;
-    }
     const long long M = (long long)B * HW;
+    const long long plane = (long long)C0 * Cin + Cin;                 // [weight sums | bias sums] per block, added in block order afterwards
+    unsigned nb;
+    float *parts;
     if (C0 <= 256) {
         const long long ntiles = (M + 255) / 256;
-        const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
-        if (Cin <= 4) hipLaunchKernelGGL(head_bwd_rows_kernel<4>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin, ntiles);
-        else if (Cin <= 8) hipLaunchKernelGGL(head_bwd_rows_kernel<8>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin, ntiles);
-        else hipLaunchKernelGGL(head_bwd_rows_kernel<16>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin, ntiles);
+        nb = (unsigned)(ntiles < 256 ? ntiles : 256);
+        parts = (float *)ldm_scratch(st, (size_t)(nb + 1) * plane * sizeof(float));
+        if (!parts) return LDM_ELAUNCH;
+        const dim3 grid(nb);
+        if (Cin <= 4) hipLaunchKernelGGL(head_bwd_rows_kernel<4>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, parts, parts, M, C0, HW, Cin, ntiles);
+        else if (Cin <= 8) hipLaunchKernelGGL(head_bwd_rows_kernel<8>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, parts, parts, M, C0, HW, Cin, ntiles);
+        else hipLaunchKernelGGL(head_bwd_rows_kernel<16>, grid, dim3(kRowsNT), 0, st, x, w, dout, dx, parts, parts, M, C0, HW, Cin, ntiles);
     } else {
-        hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(M, 64)), dim3(256), 0, st, x, w, dout, dx, dw, db, M, C0, HW, Cin);
+        nb = blocks_for(M, 64);
+        parts = (float *)ldm_scratch(st, (size_t)(nb + 1) * plane * sizeof(float));
+        if (!parts) return LDM_ELAUNCH;
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(nb), dim3(256), 0, st, x, w, dout, dx, parts, parts, M, C0, HW, Cin);
+    }
+    // one fixed-order sum over the planes into a contiguous [C0 * Cin + Cin] vector (the first spare cells behind the planes), then two copies
+    float *sum = parts + (long long)nb * plane;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(plane, 256)), dim3(256), 0, st, (const float *)parts, sum, (int)nb, plane);
+    if (hipMemcpyAsync(dw, sum, (size_t)C0 * Cin * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(db, sum + (long long)C0 * Cin, (size_t)Cin * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        ldm_set_error("ldm_head_bwd_f32: copy of the summed gradients failed");
+        return LDM_ELAUNCH;
     }
     LDM_CHECK_LAUNCH("ldm_head_bwd_f32");
     return LDM_OK;
@@ -1231,10 +1321,12 @@ extern "C" int ldm_l1_loss_f32(const float *pred, const float *target, long long
 {
     LDM_REQUIRE(pred && target && loss && n > 0, "ldm_l1_loss_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_l1_loss_f32: memset failed"); return LDM_ELAUNCH; }
     unsigned blocks = blocks_for(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, st, pred, target, n, 1.0f / (float)n, loss);
+    float *parts = (float *)ldm_scratch(st, blocks * sizeof(float));
+    if (!parts) return LDM_ELAUNCH;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, st, pred, target, n, parts);
+    hipLaunchKernelGGL(l1_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)parts, (int)blocks, 1.0f / (float)n, loss);
     LDM_CHECK_LAUNCH("ldm_l1_loss_f32");
     return LDM_OK;
 }
@@ -1284,7 +1376,8 @@ extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_pr
     }
     p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dbias_pad, 0, (size_t)3 * C * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_window_attention_bwd_f32: memset failed"); return LDM_ELAUNCH; }
+    p.pad_parts = (float *)ldm_scratch(st, (size_t)p.total_waves * 64 * sizeof(float));
+    if (!p.pad_parts) return LDM_ELAUNCH;
     const dim3 grid((unsigned)((p.total_waves + 1) / 2));
     if (g_attn_bwd_mfma) {                              // every window the reference builds has L <= 36
         const int nt = (p.L + 15) / 16;
@@ -1297,6 +1390,7 @@ extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_pr
         const size_t smem = 2ull * (2 * LMAX * 36 + 2 * LMAX * (LMAX + 1) + LMAX + 4) * sizeof(float);
         hipLaunchKernelGGL(window_attention_bwd_kernel<LMAX>, grid, dim3(128), smem, st, p);
     }
+    hipLaunchKernelGGL(attn_pad_finish_kernel, dim3(p.heads), dim3(1024), 0, st, (const float *)p.pad_parts, p.total_waves / p.heads, p.heads, C, dbias_pad);
     LDM_CHECK_LAUNCH("ldm_window_attention_bwd_f32");
     return LDM_OK;
 }

@@ -21,6 +21,9 @@ void ldm_set_error(const char *fmt, ...);
 void *ldm_prof_begin(int cls, double flops, hipStream_t st, double bytes = 0.0);      // NULL when profiling is off; bytes = algorithmic HBM bytes
 void ldm_prof_end(void *h, hipStream_t st);
 
+// grow-only device scratch of this (device, stream) for fixed-order partial sums (scratch.cpp); NULL (and ldm_last_error set) on failure
+void *ldm_scratch(hipStream_t st, size_t bytes);
+
 #define LDM_REQUIRE(cond, ...)                 \
     do {                                       \
         if (!(cond)) {                         \

@@ -94,3 +94,23 @@ extern "C" int ldm_prof_read(long long *launches, double *ms, double *flops)
     g_used = 0;
     return rc;
 }
+
+// every record of the pool in launch order: out[4 i .. 4 i + 3] = (class, kernel ms, algorithmic FLOPs, algorithmic bytes); returns the
+// number of records written (at most max_records), negative on error.  Does not clear (tools: per-shape census of a forward).
+extern "C" long long ldm_prof_dump(double *out, long long max_records)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    long long n = 0;
+    for (size_t i = 0; i < g_used && n < max_records; ++i, ++n) {
+        float e = 0.f;
+        if (hipEventSynchronize(g_pool[i].stop) != hipSuccess || hipEventElapsedTime(&e, g_pool[i].start, g_pool[i].stop) != hipSuccess) {
+            ldm_set_error("ldm_prof_dump: event %zu not readable", i);
+            return LDM_ELAUNCH;
+        }
+        out[4 * n] = g_pool[i].cls;
+        out[4 * n + 1] = e;
+        out[4 * n + 2] = g_pool[i].flops;
+        out[4 * n + 3] = g_pool[i].bytes;
+    }
+    return n;
+}

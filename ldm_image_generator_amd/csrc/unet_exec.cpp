@@ -9,6 +9,7 @@
 // (stochastic depth, expert choice), handed over as one int per block.
 #include "common.h"
 #include <cstring>
+#include <cstdlib>
 
 extern "C" {
 int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
@@ -92,6 +93,19 @@ bool levels_of(const ldm_unet_plan *pl, int B, int H, int W, int nT, Level *lv)
     return true;
 }
 
+// chunking knob of run_stack (bytes of one fp32 activation per chunk; 0 = whole batch).  LDM_UNET_CHUNK_MB overrides (A/B runs).
+long long g_chunk_mb[2] = {0, 0};            // [fp32 mode, bf16 mode]
+long long unet_chunk_bytes(bool bf16)
+{
+    static int env = -2;
+    if (env == -2) {
+        const char *e = getenv("LDM_UNET_CHUNK_MB");
+        env = e ? atoi(e) : -1;
+    }
+    const long long mb = env >= 0 ? env : g_chunk_mb[bf16 ? 1 : 0];
+    return mb << 20;
+}
+
 #define RUN(call)                    \
     do {                             \
         const int rc_ = (call);      \
@@ -140,9 +154,9 @@ int run_block_bf16(const ldm_unet_plan *pl, const ldm_unet_block *bk, const ldm_
     RUN(ldm_channelnorm_film_bf16(x, film, slot, nullptr, xf16, B, lv.H * lv.W, C, pl->eps, st));
     RUN(ldm_gconv3x3_bf16(xf16, b16->conv_w, bk->conv_b, x, y, B, lv.H, lv.W, C, st));           // y = conv3x3_grouped(xf) + bias + x
     if (bk->attention) {
-        ldm_gemm_desc q = gemm_rows16(xf16, M, 3 * C, C, b16->in_w, bk->in_b, L.qkv);
-        RUN(ldm_gemm_bf16(&q, 0, st));
-        RUN(ldm_window_attention_bf16io(L.qkv, bk->in_b, xf16, ctx16, B, lv.H, lv.W, C, pl->window, bk->shift, st));
+        ldm_gemm_desc q = gemm_rows16(xf16, M, 3 * C, C, b16->in_w, bk->in_b, L.qkv);           // q, k, v as bf16 rows (half the bytes each way)
+        RUN(ldm_gemm_bf16(&q, 1, st));
+        RUN(ldm_window_attention_bf16io(L.qkv, 1, bk->in_b, xf16, ctx16, B, lv.H, lv.W, C, pl->window, bk->shift, st));
         ldm_gemm_desc o = gemm_rows16(ctx16, M, C, C, b16->out_w, bk->out_b, y);
         o.addend = y; o.ldadd = C;
         RUN(ldm_gemm_bf16(&o, 0, st));
@@ -291,6 +305,46 @@ static int unet_forward_impl(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *
     }
     auto film_of = [&](int level, int k) { return L.film[level] + (size_t)k * lv[level].Mf * 2 * lv[level].C; };
 
+    // One stack of SwinBlocks (blocks blk0 .. blk0 + nblk of the plan, FiLM tables film_k0 ...) at `level`, starting from activation buffer
+    // `cur`; returns through `cur` the buffer that holds the result.  Samples never interact, so the stack may run over the
+    // batch in CHUNKS of samples, chunk by chunk through ALL its blocks: with chunk_bytes > 0 a chunk is sized so that one fp32
+    // activation of it takes at most that many bytes, which keeps a chunk's tensors (input, normalised copy, gated hidden, output --
+    // and the block-to-block hand-over) inside the 256-MiB Infinity Cache instead of streaming them through HBM between launches.
+    // Same kernels on the same rows: results do not depend on the chunking beyond the tile paths a different M selects.
+    const long long chunk_bytes = unet_chunk_bytes(p16 != nullptr);
+    auto run_stack = [&](int level, int blk0, int nblk, int film_k0, int &cur_buf) -> int {
+        const Level &full = lv[level];
+        const long long per_sample = (long long)full.H * full.W * full.C * (long long)sizeof(float);
+        int bc = B;
+        if (chunk_bytes > 0 && per_sample * B > chunk_bytes) {
+            bc = (int)(chunk_bytes / per_sample);
+            bc = bc < 1 ? 1 : bc;
+            const int nchunks = (B + bc - 1) / bc;
+            bc = (B + nchunks - 1) / nchunks;                                   // balanced chunks
+        }
+        int last = cur_buf;
+        for (int b0 = 0; b0 < B; b0 += bc) {
+            const int bn = B - b0 < bc ? B - b0 : bc;
+            Level part = full;
+            part.M = (long long)bn * full.H * full.W;
+            const size_t off = (size_t)b0 * full.H * full.W * full.C;
+            int c = cur_buf;
+            for (int k = 0; k < nblk; ++k) {
+                const int dcs = decisions[blk0 + k];
+                if (dcs < 0) continue;                                          // stochastic depth (unet.py:39-40)
+                const int nxt = (c + 1) % 3;
+                const float *film = film_of(level, film_k0 + k);
+                const int *sl = slot ? slot + b0 : nullptr;
+                if (p16) RUN(run_block_bf16(pl, pl->blocks + blk0 + k, p16->blocks + blk0 + k, dcs, film, sl, L.act[level][c] + off, L.act[level][nxt] + off, part, bn, L, st));
+                else RUN(run_block(pl, pl->blocks + blk0 + k, dcs, film, sl, L.act[level][c] + off, L.act[level][nxt] + off, part, bn, L, st));
+                c = nxt;
+            }
+            last = c;
+        }
+        cur_buf = last;
+        return LDM_OK;
+    };
+
     // ---- stem -------------------------------------------------------------------------------------------
     int cur[LDM_MAX_LEVELS];                                   // which of the 3 activation buffers holds the live tensor
     for (int i = 0; i < n; ++i) cur[i] = 0;
@@ -298,14 +352,7 @@ static int unet_forward_impl(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *
     int skip_buf[LDM_MAX_LEVELS];
     // ---- encoder ----------------------------------------------------------------------------------------
     for (int i = 0; i < n; ++i) {
-        for (int k = 0; k < pl->enc_blocks[i]; ++k) {
-            const int dcs = decisions[enc0[i] + k];
-            if (dcs < 0) continue;                                          // stochastic depth (unet.py:39-40)
-            const int nxt = (cur[i] + 1) % 3;
-            if (p16) RUN(run_block_bf16(pl, pl->blocks + enc0[i] + k, p16->blocks + enc0[i] + k, dcs, film_of(i, k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
-            else RUN(run_block(pl, pl->blocks + enc0[i] + k, dcs, film_of(i, k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
-            cur[i] = nxt;
-        }
+        RUN(run_stack(i, enc0[i], pl->enc_blocks[i], 0, cur[i]));
         skip_buf[i] = cur[i];
         if (i + 1 < n) {                                                    // unet.py:83, pool commuted in front of the 1x1 conv
             RUN(ldm_avgpool2_f32(L.act[i][cur[i]], L.pooled, B, lv[i].H, lv[i].W, lv[i].C, st));
@@ -324,14 +371,7 @@ static int unet_forward_impl(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *
             RUN(ldm_gemm_f32(&d, st));
             cur[i] = dst;
         }
-        for (int k = 0; k < pl->dec_blocks[i]; ++k) {
-            const int dcs = decisions[dec0[i] + k];
-            if (dcs < 0) continue;
-            const int nxt = (cur[i] + 1) % 3;
-            if (p16) RUN(run_block_bf16(pl, pl->blocks + dec0[i] + k, p16->blocks + dec0[i] + k, dcs, film_of(i, pl->enc_blocks[i] + k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
-            else RUN(run_block(pl, pl->blocks + dec0[i] + k, dcs, film_of(i, pl->enc_blocks[i] + k), slot, L.act[i][cur[i]], L.act[i][nxt], lv[i], B, L, st));
-            cur[i] = nxt;
-        }
+        RUN(run_stack(i, dec0[i], pl->dec_blocks[i], pl->enc_blocks[i], cur[i]));
     }
     RUN(ldm_head_nchw_f32(L.act[0][cur[0]], pl->head_w, pl->head_b, out, B, lv[0].C, H * W, pl->input_channels, st));
     return LDM_OK;

@@ -51,10 +51,9 @@ __global__ void space_to_depth2_kernel(const f32x4 *__restrict__ fine, f32x4 *__
     out[i] = fine[fp * C4 + c4];
 }
 
-// rgb head backward, per pixel: drows[p][c] (+)= sum_j drgb[b][j][pix] w[j][c]; and the adjoint of the bilinear x2 accumulation
-// (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False), vae.py:131) scattered into dprev with atomics
+// rgb head backward, per pixel: drows[p][c] (+)= sum_j drgb[b][j][pix] w[j][c]
 __global__ __launch_bounds__(256) void rgb_head_bwd_kernel(const float *__restrict__ drgb, const float *__restrict__ w, float *__restrict__ drows,
-                                                           float *__restrict__ dprev, int B, int H, int W, int C, int accumulate)
+                                                           int B, int H, int W, int C, int accumulate)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -71,27 +70,55 @@ __global__ __launch_bounds__(256) void rgb_head_bwd_kernel(const float *__restri
         for (int e = 0; e < 4; ++e) o[e] += (g0 * w0[e] + g1 * w1[e]) + g2 * w2[e];
         dr[c4] = o;
     }
-    if (dprev && lane < 12) {                                 // 3 channels x 4 source pixels
-        const int y = pix / W, xx = pix - y * W;
-        const int PH = H >> 1, PW = W >> 1;
-        float sy = 0.5f * (float)y - 0.25f, sx = 0.5f * (float)xx - 0.25f;
-        sy = sy < 0.f ? 0.f : sy;
-        sx = sx < 0.f ? 0.f : sx;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < PH - 1 ? 1 : 0), x1 = x0 + (x0 < PW - 1 ? 1 : 0);
-        const float ly = sy - (float)y0, lx = sx - (float)x0;
-        const int j = lane >> 2, corner = lane & 3;
-        const float wy = (corner >> 1) ? ly : 1.f - ly, wx = (corner & 1) ? lx : 1.f - lx;
-        const int py = (corner >> 1) ? y1 : y0, px = (corner & 1) ? x1 : x0;
-        const float g = j == 0 ? g0 : (j == 1 ? g1 : g2);
-        atomicAdd(dprev + (b * 3 + j) * PH * PW + py * PW + px, g * wy * wx);
-    }
 }
 
-// dw[j][c] += sum_p drgb[p][j] rows[p][c], db[j] += sum_p drgb[p][j]  over a slab of pixels per block (atomics into zeroed buffers)
-__global__ __launch_bounds__(256) void rgb_head_wgrad_kernel(const float *__restrict__ drgb, const float *__restrict__ rows, float *__restrict__ dw,
-                                                             float *__restrict__ db, int B, int HW, int C, int slab)
+// The adjoint of the bilinear x2 accumulation (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False), vae.py:131) as a
+// GATHER: a thread owns one coarse cell (b, j, py, px) and walks the fine pixels that can touch it (rows 2 py - 2 ... 2 py + 3, same
+// for columns) in a fixed order, adding the corner weights of those whose source cell it is.  No atomics: bit-reproducible.
+__global__ __launch_bounds__(256) void bilinear2x_adjoint_kernel(const float *__restrict__ drgb, float *__restrict__ dprev, int B, int H, int W)
 {
+    const int PH = H >> 1, PW = W >> 1;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * 3 * PH * PW) return;
+    const int px = (int)(i % PW);
+    const int py = (int)((i / PW) % PH);
+    const long long bj = i / ((long long)PW * PH);
+    const float *g = drgb + bj * H * W;
+    float acc = 0.f;
+    for (int y = 2 * py - 2; y <= 2 * py + 3; ++y) {
+        if (y < 0 || y >= H) continue;
+        float sy = 0.5f * (float)y - 0.25f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = (int)sy, y1 = y0 + (y0 < PH - 1 ? 1 : 0);
+        const float ly = sy - (float)y0;
+        if (y0 != py && y1 != py) continue;
+        for (int x = 2 * px - 2; x <= 2 * px + 3; ++x) {
+            if (x < 0 || x >= W) continue;
+            float sx = 0.5f * (float)x - 0.25f;
+            sx = sx < 0.f ? 0.f : sx;
+            const int x0 = (int)sx, x1 = x0 + (x0 < PW - 1 ? 1 : 0);
+            const float lx = sx - (float)x0;
+            if (x0 != px && x1 != px) continue;
+            const float gv = g[y * W + x];
+#pragma unroll
+            for (int corner = 0; corner < 4; ++corner) {
+                const int cy = (corner >> 1) ? y1 : y0, cx = (corner & 1) ? x1 : x0;
+                if (cy != py || cx != px) continue;
+                const float wy = (corner >> 1) ? ly : 1.f - ly, wx = (corner & 1) ? lx : 1.f - lx;
+                acc += gv * wy * wx;
+            }
+        }
+    }
+    dprev[i] = acc;
+}
+
+// dw[j][c] = sum_p drgb[p][j] rows[p][c], db[j] = sum_p drgb[p][j]: a block sums its slab of pixels into ITS plane of `parts`
+// ([blocks][3 C + 3]: weight sums, then the three bias sums); sum_planes_kernel adds the planes in block order (no atomics)
+__global__ __launch_bounds__(256) void rgb_head_wgrad_kernel(const float *__restrict__ drgb, const float *__restrict__ rows, float *__restrict__ parts,
+                                                             int B, int HW, int C, int slab)
+{
+    float *dw = parts + (long long)blockIdx.x * (3 * C + 3);
+    float *db = dw + 3 * C;
     const long long total = (long long)B * HW;
     const long long p0 = (long long)blockIdx.x * slab;
     const long long p1 = p0 + slab < total ? p0 + slab : total;
@@ -109,15 +136,27 @@ __global__ __launch_bounds__(256) void rgb_head_wgrad_kernel(const float *__rest
             s1 += g1;
             s2 += g2;
         }
-        atomicAdd(dw + c, a0);
-        atomicAdd(dw + C + c, a1);
-        atomicAdd(dw + 2 * C + c, a2);
+        dw[c] = a0;
+        dw[C + c] = a1;
+        dw[2 * C + c] = a2;
         if (c == 0) {
-            atomicAdd(db + 0, s0);
-            atomicAdd(db + 1, s1);
-            atomicAdd(db + 2, s2);
+            db[0] = s0;
+            db[1] = s1;
+            db[2] = s2;
         }
     }
+}
+
+// dw[i] (i < 3 C) and db[i - 3 C] = sum over planes of parts[plane][i], in plane order
+__global__ __launch_bounds__(256) void sum_planes_kernel(const float *__restrict__ parts, int nplanes, int C, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = 3 * C + 3;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nplanes; ++k) s += parts[(long long)k * n + i];
+    if (i < 3 * C) dw[i] = s;
+    else db[i - 3 * C] = s;
 }
 
 }  // namespace
@@ -163,9 +202,16 @@ extern "C" int ldm_rgb_head_bwd_f32(const float *drgb, const float *w, const flo
     LDM_REQUIRE(ldm_aligned16(w) && ldm_aligned16(drows), "ldm_rgb_head_bwd_f32: unaligned pointer");
     const long long rowsn = (long long)B * H * W;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(rgb_head_bwd_kernel, dim3(vb_blocks(rowsn, 4)), dim3(256), 0, st, drgb, w, drows, dprev, B, H, W, C, accumulate);
-    const int slab = 256;
-    hipLaunchKernelGGL(rgb_head_wgrad_kernel, dim3(vb_blocks(rowsn, slab)), dim3(256), 0, st, drgb, rows, dw, db, B, H * W, C, slab);
+    hipLaunchKernelGGL(rgb_head_bwd_kernel, dim3(vb_blocks(rowsn, 4)), dim3(256), 0, st, drgb, w, drows, B, H, W, C, accumulate);
+    if (dprev)
+        hipLaunchKernelGGL(bilinear2x_adjoint_kernel, dim3(vb_blocks((long long)B * 3 * (H / 2) * (W / 2), 256)), dim3(256), 0, st, drgb, dprev, B, H, W);
+    long long slab = (rowsn + 511) / 512;                                 // at most ~512 planes for the fixed-order sum
+    slab = slab < 256 ? 256 : slab;
+    const unsigned nb = vb_blocks(rowsn, (int)slab);
+    float *parts = (float *)ldm_scratch(st, (size_t)nb * (3 * C + 3) * sizeof(float));
+    if (!parts) return LDM_ELAUNCH;
+    hipLaunchKernelGGL(rgb_head_wgrad_kernel, dim3(nb), dim3(256), 0, st, drgb, rows, parts, B, H * W, C, (int)slab);
+    hipLaunchKernelGGL(sum_planes_kernel, dim3((3 * C + 3 + 255) / 256), dim3(256), 0, st, (const float *)parts, (int)nb, C, dw, db);
     LDM_CHECK_LAUNCH("ldm_rgb_head_bwd_f32");
     return LDM_OK;
 }

@@ -77,7 +77,9 @@ __global__ void vq_embed_kernel(const long long *__restrict__ idx, const float *
 }
 
 // loss[0] = mean |x - e| + mean |e - x|  (vae.py:12-16: reg_loss + embedding_loss, each an F.l1_loss over M * D elements)
-__global__ __launch_bounds__(256) void vq_loss_kernel(const float *__restrict__ x, const float *__restrict__ e, long long n, float inv_n, float *__restrict__ loss)
+// Per-block sums go to `parts` (one float per block); vq_loss_finish_kernel adds them in block order -- no float atomics, so the loss is
+// bit-reproducible from run to run.
+__global__ __launch_bounds__(256) void vq_loss_kernel(const float *__restrict__ x, const float *__restrict__ e, long long n, float *__restrict__ parts)
 {
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += fabsf(x[i] - e[i]);
@@ -85,21 +87,46 @@ __global__ __launch_bounds__(256) void vq_loss_kernel(const float *__restrict__ 
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, 2.0f * inv_n * (part[0] + part[1] + part[2] + part[3]));
+    if (threadIdx.x == 0) parts[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-// dx = g * sign(x - e) / n (reg_loss, e detached);  demb[idx[m]] += g * sign(e - x) / n (embedding_loss, x detached)
+// one block: loss = 2 / n * (sum of the per-block sums: fixed strided partial sums, then a fixed tree)
+__global__ __launch_bounds__(256) void vq_loss_finish_kernel(const float *__restrict__ parts, int nparts, float inv_n, float *__restrict__ loss)
+{
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += parts[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = 2.0f * inv_n * sh[0];
+}
+
+// dx = g * sign(x - e) / n (reg_loss, e detached);  demb[idx[m]] += g * sign(e - x) / n (embedding_loss, x detached).
+// Every contribution to a codebook cell is +-(g / n) or 0, so the cell's sum is an INTEGER count times g / n: the counts are
+// accumulated with integer atomics (associative: independent of the order of arrival) in the cells themselves and
+// vq_demb_finish_kernel multiplies once -- bit-reproducible, unlike a float scatter-add.
 __global__ void vq_loss_bwd_kernel(const float *__restrict__ x, const float *__restrict__ e, const long long *__restrict__ idx, const float *__restrict__ g,
-                                   float inv_n, float *__restrict__ dx, float *__restrict__ demb, long long M, int D)
+                                   float inv_n, float *__restrict__ dx, int *__restrict__ counts, long long M, int D)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * D) return;
     const float d = x[i] - e[i];
-    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    const float v = g[0] * inv_n * sg;
-    dx[i] = v;
+    const int sg = d > 0.f ? 1 : (d < 0.f ? -1 : 0);
+    dx[i] = (g[0] * inv_n) * (float)sg;
     const long long m = i / D;
-    atomicAdd(demb + idx[m] * D + (i - m * D), -v);
+    if (sg) atomicAdd(counts + idx[m] * D + (i - m * D), -sg);
+}
+
+__global__ void vq_demb_finish_kernel(float *__restrict__ demb, const float *__restrict__ g, float inv_n, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = ((const int *)demb)[i];                              // the counts sit in the gradient's own 4-byte cells
+    demb[i] = (g[0] * inv_n) * (float)c;
 }
 
 }  // namespace
@@ -129,10 +156,12 @@ extern "C" int ldm_vq_loss_f32(const float *x, const float *e, long long n, floa
 {
     LDM_REQUIRE(x && e && loss && n > 0, "ldm_vq_loss_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_vq_loss_f32: memset failed"); return LDM_ELAUNCH; }
     unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(vq_loss_kernel, dim3(blocks), dim3(256), 0, st, x, e, n, 1.0f / (float)n, loss);
+    float *parts = (float *)ldm_scratch(st, blocks * sizeof(float));
+    if (!parts) return LDM_ELAUNCH;
+    hipLaunchKernelGGL(vq_loss_kernel, dim3(blocks), dim3(256), 0, st, x, e, n, parts);
+    hipLaunchKernelGGL(vq_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)parts, (int)blocks, 1.0f / (float)n, loss);
     LDM_CHECK_LAUNCH("ldm_vq_loss_f32");
     return LDM_OK;
 }
@@ -143,7 +172,8 @@ extern "C" int ldm_vq_loss_bwd_f32(const float *x, const float *e, const long lo
     LDM_REQUIRE(x && e && idx && gscale && dx && demb && M > 0 && N > 0 && D > 0, "ldm_vq_loss_bwd_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(demb, 0, (size_t)N * D * sizeof(float), st) != hipSuccess) { ldm_set_error("ldm_vq_loss_bwd_f32: memset failed"); return LDM_ELAUNCH; }
-    hipLaunchKernelGGL(vq_loss_bwd_kernel, dim3((unsigned)((M * D + 255) / 256)), dim3(256), 0, st, x, e, idx, gscale, 1.0f / (float)(M * D), dx, demb, M, D);
+    hipLaunchKernelGGL(vq_loss_bwd_kernel, dim3((unsigned)((M * D + 255) / 256)), dim3(256), 0, st, x, e, idx, gscale, 1.0f / (float)(M * D), dx, (int *)demb, M, D);
+    hipLaunchKernelGGL(vq_demb_finish_kernel, dim3((unsigned)(((long long)N * D + 255) / 256)), dim3(256), 0, st, demb, gscale, 1.0f / (float)(M * D), (long long)N * D);
     LDM_CHECK_LAUNCH("ldm_vq_loss_bwd_f32");
     return LDM_OK;
 }

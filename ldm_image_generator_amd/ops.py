@@ -578,9 +578,11 @@ def film_hidden_bwd(dh, hid, B, HW, N):
 
 # ---- bf16 sampling / decode (include/ldm_hip.h, "bf16 sampling / decode") ------------------------------------
 def window_attention_bf16io(qkv, in_proj_bias, xf16, out16, B, H, W, C, ws, shift):
-    """window_attention on the fp32 QKV of a bf16 in-projection: float "mask" read from the bf16 normalised input, bf16 context out."""
-    _call("ldm_window_attention_bf16io", _dev(qkv, "qkv"), _dev(in_proj_bias, "in_proj_bias"), _opt(xf16, "xf16", BF16), _dev(out16, "out", BF16),
-          B, H, W, C, ws, shift)
+    """window_attention behind a bf16 in-projection (qkv fp32 or bf16 by its dtype): float "mask" read from the bf16 normalised
+    input, bf16 context out."""
+    q16 = qkv.dtype == BF16
+    _call("ldm_window_attention_bf16io", _dev(qkv, "qkv", BF16 if q16 else torch.float32), int(q16), _dev(in_proj_bias, "in_proj_bias"),
+          _opt(xf16, "xf16", BF16), _dev(out16, "out", BF16), B, H, W, C, ws, shift)
     return out16
 
 

@@ -79,20 +79,23 @@ def test_gate_forward_hidden_only_ring_equals_stream(gpu_device, M, C, nseg):
     assert rel_l2(outs[0].float().cpu(), a * b_.clamp_min(0)) < ULP_TOL
 
 
+@pytest.mark.parametrize("q16", [False, True])
 @pytest.mark.parametrize("shift", [0, 3])
 @pytest.mark.parametrize("hw", [(8, 8), (16, 16), (4, 4), (7, 9)])
-def test_window_attention_bf16io(gpu_device, shift, hw):
+def test_window_attention_bf16io(gpu_device, shift, hw, q16):
+    """bf16 I/O around the fp32 attention core: with the same (bf16-representable) QKV, bias and mask values the context equals the
+    fp32 kernel's, rounded once."""
     from ldm_image_generator_amd import ops
     B, C = 3, 64
     H, W = hw
     g = torch.Generator().manual_seed(H * 10 + W + shift)
-    qkv = torch.randn(B * H * W, 3 * C, generator=g).cuda()
-    bias = torch.randn(3 * C, generator=g).cuda()
+    qkv = bf(torch.randn(B * H * W, 3 * C, generator=g)).cuda()
+    bias = bf(torch.randn(3 * C, generator=g)).float().cuda()                     # padded tokens take bf16(bias) in the bf16-QKV form
     xf = bf(torch.randn(B * H * W, C, generator=g)).cuda()
     ref = torch.empty(B * H * W, C, device=gpu_device)
-    ops.window_attention(qkv, bias, xf.float(), ref, B, H, W, C, 6, shift)          # same mask values: the bf16 xf, widened exactly
+    ops.window_attention(qkv.float(), bias, xf.float(), ref, B, H, W, C, 6, shift)
     out = torch.empty(B * H * W, C, device=gpu_device, dtype=BF)
-    ops.window_attention_bf16io(qkv, bias, xf, out, B, H, W, C, 6, shift)
+    ops.window_attention_bf16io(qkv if q16 else qkv.float(), bias, xf, out, B, H, W, C, 6, shift)
     assert torch.equal(out, bf(ref))
 
 
