@@ -274,10 +274,10 @@ def main():
         try:
             dta, _, outa = measure(1, sec_steps * 2, prof=False)
             # a second, profiled pass set for the per-class kernel times (hipEvents around every MFMA launch slow short kernels down a little)
+            ops.prof_enable(rank == 0)
+            one_pass(100 + args.steps - 1)                       # every rank: the pass ends in the all-gather
+            fence()
             if rank == 0:
-                ops.prof_enable(True)
-                one_pass(100 + args.steps - 1)
-                torch.cuda.synchronize()
                 per, tot_ms, tot_fl, tot_by = {}, 0.0, 0.0, 0.0
                 for cls, name in PROF_CLASSES.items():
                     n, ms, fl = ops.prof_read_class(cls)
@@ -287,7 +287,7 @@ def main():
                                      "algorithmic_gb_per_s": by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None}
                         tot_ms, tot_fl, tot_by = tot_ms + ms, tot_fl + fl, tot_by + by
                 ops.prof_read()
-                ops.prof_enable(False)
+            ops.prof_enable(False)
         finally:
             autocast.set_autocast_dtype(net, None)
             autocast.set_compute_dtype(dec, None)
