@@ -305,6 +305,11 @@ int ldm_window_attention_bwd_mfma(int v);
  * d->a_mode == LDM_A_CONV3X3 (bf16 output only): dense 3x3, zero pad 1, over bf16 rows [M = B*H*W, Cin], Cin a multiple of 64,
  * K = 9*Cin, weights packed [N][tap][Cin] bf16 (vae.py:57-58 under autocast).  Rows out only, no gate. */
 int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream);
+/* ldm_window_attention_bwd_f32 with bf16 rows around the fp32 core: qkv [B,H,W,3C], xf (float "mask" source, NULL if shift == 0) and
+ * dctx [B,H,W,C] are bf16, dqkv [B,H,W,3C] leaves as bf16; zero-padded tokens take the bias rounded to bf16 (what the bf16
+ * in-projection of a zero row stores); dbias_pad [3C] stays fp32. */
+int ldm_window_attention_bwd_bf16(const void *qkv, const float *in_proj_bias, const void *xf, const void *dctx, void *dqkv, float *dbias_pad,
+                                  int B, int H, int W, int C, int ws, int shift, void *stream);
 /* ReGLU forward in one launch (modules.py:14-15): d->act == LDM_ACT_GATE, d->w / d->w2 (+ bias / bias2) the "a" / "b" branches,
  * d->out = a * relu(b) as bf16 [M, ldo]; a_pre / b_pre (both or neither): bf16 [M, ldo] copies of the pre-activations a, b that
  * the backward needs.  ldm_gemm_bf16_gate_bwd is the data-gradient GEMM dh = dy . Wc (d as for ldm_gemm_bf16) with the gate's
@@ -390,6 +395,11 @@ typedef struct ldm_cast_job {
     long long    rows;
     int          cols;
 } ldm_cast_job;
+/* Both bf16 filter tables of the grouped 3x3 conv from conv.weight [C, 32, 3, 3] fp32 in one launch: fwd [C][tap][ci] (the forward's
+ * operand) and rot [g*32 + ci][mirrored tap][co] (the data gradient's: the flipped, in/out-swapped filter). */
+int ldm_gconv_pack_bf16(const float *w, void *fwd_bf16, void *rot_bf16, int C, void *stream);
+/* out[r][0..n) = src[0..n) for r < reps (one gradient shared by several biases, as separate rows) */
+int ldm_replicate_f32(const float *src, float *out, int n, int reps, void *stream);
 size_t ldm_multi_cast_table_bytes(int njobs);
 int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, int rebuild, long long *tiles_io, void *stream);
 

@@ -145,6 +145,7 @@ SIGNATURES = {
     "ldm_window_attention_bwd_mfma": (_I, [_I]),
     # bf16 training step
     "ldm_gemm_bf16": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
+    "ldm_window_attention_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ldm_gemm_bf16_gate_fwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P]),
     "ldm_gemm_bf16_gate_bwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P, _P]),
     "ldm_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
@@ -168,6 +169,8 @@ SIGNATURES = {
     "ldm_im2col3x3_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_space_to_depth2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_rgb_head_bwd_f32": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_gconv_pack_bf16": (_I, [_P, _P, _P, _I, _P]),
+    "ldm_replicate_f32": (_I, [_P, _P, _I, _I, _P]),
     "ldm_multi_cast_table_bytes": (ctypes.c_size_t, [_I]),
     "ldm_multi_cast_bf16": (_I, [ctypes.POINTER(CastJob), _I, _P, _I, ctypes.POINTER(_L), _P]),
     "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -586,6 +586,10 @@ __global__ __launch_bounds__(256) void im2col3x3_t_kernel(const float *__restric
 struct AttnB {
     const float *qkv, *bias, *xf, *dctx;
     float *dqkv, *dbias_pad;
+    // bf16 training step: q, k, v / dO arrive as bf16 rows and dq, dk, dv leave as bf16 rows (then the fp32 pointers above are NULL); the
+    // float "mask" of shifted windows comes from the bf16 normalised input.  The arithmetic in between is unchanged (fp32 MFMA).
+    const unsigned short *qkv16, *dctx16, *xf16;
+    unsigned short *dqkv16;
     float *pad_parts;            // [total_waves][64]: every wave's (dk | dv) sums over ITS zero-padded tokens (zeros if it has none); added per
                                  // head in wave order by attn_pad_finish_kernel -- no float atomics, the bias gradient is bit-reproducible
     int B, H, W, C, ws, shift;
@@ -795,6 +799,29 @@ __global__ __launch_bounds__(128) void window_attention_bwd_kernel(const AttnB p
     }
 }
 
+// eight consecutive values of a bf16 row, widened exactly
+__device__ __forceinline__ void widen8(const unsigned short *src, f32x4 &lo, f32x4 &hi)
+{
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const u32x4v w = *(const u32x4v *)src;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        lo[2 * e] = __uint_as_float(w[e] << 16);
+        lo[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+        hi[2 * e] = __uint_as_float(w[2 + e] << 16);
+        hi[2 * e + 1] = __uint_as_float(w[2 + e] & 0xFFFF0000u);
+    }
+}
+// four fp32 values -> four bf16 (RNE), one 8-byte store
+__device__ __forceinline__ void store4_bf16(unsigned short *dst, const f32x4 &v)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const f32x2v a = {v[0], v[1]}, b = {v[2], v[3]};
+    *(u32x2v *)dst = u32x2v{__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2v))};
+}
+
 // ---- MFMA version (v_mfma_f32_16x16x4_f32, exact fp32; every window of the reference: L <= 48) ----------------------------------
 // One wave per (sample, window, head) as above, but the five products run on the matrix pipe (the scalar kernel is VALU-bound:
 // 1.6 ms at the cfg-5 stage-0 shape against an HBM floor of 0.4 ms).  Operand conventions of the forward kernel
@@ -847,16 +874,42 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
             tok[t] = ok;
             tpad[t] = j < L && !ok;
             trow[t] = img + (long long)sy * p.W + sx;
-            const float *row = ok ? p.qkv + trow[t] * 3 * C + head * 32 : p.bias + head * 32;
+            f32x4 qv2[2];
+            if (p.qkv16) {
+                if (ok) {
+                    const unsigned short *row16 = p.qkv16 + trow[t] * 3 * C + head * 32 + 8 * g;
+                    widen8(row16, qv2[0], qv2[1]);
+                    widen8(row16 + C, kf[t][0], kf[t][1]);
+                    widen8(row16 + 2 * C, vf[t][0], vf[t][1]);
+                    widen8(p.dctx16 + trow[t] * C + head * 32 + 8 * g, gf[t][0], gf[t][1]);
+                } else {                                   // zero-padded token: q, k, v = the bias as the bf16 projection stored it; dO = 0
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float *bq = p.bias + head * 32 + 8 * g + 4 * u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            qv2[u][e] = (float)(__bf16)bq[e];
+                            kf[t][u][e] = (float)(__bf16)bq[C + e];
+                            vf[t][u][e] = (float)(__bf16)bq[2 * C + e];
+                            gf[t][u][e] = 0.f;
+                        }
+                    }
+                }
+            } else {
+                const float *row = ok ? p.qkv + trow[t] * 3 * C + head * 32 : p.bias + head * 32;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 z{0.f, 0.f, 0.f, 0.f};
+                    qv2[u] = *(const f32x4 *)(row + 8 * g + 4 * u);
+                    kf[t][u] = *(const f32x4 *)(row + C + 8 * g + 4 * u);
+                    vf[t][u] = *(const f32x4 *)(row + 2 * C + 8 * g + 4 * u);
+                    gf[t][u] = ok ? *(const f32x4 *)(p.dctx + trow[t] * C + head * 32 + 8 * g + 4 * u) : z;   // cropped outputs: dO = 0
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const f32x4 z{0.f, 0.f, 0.f, 0.f};
-                const f32x4 qv = *(const f32x4 *)(row + 8 * g + 4 * u);
-                kf[t][u] = *(const f32x4 *)(row + C + 8 * g + 4 * u);
-                vf[t][u] = *(const f32x4 *)(row + 2 * C + 8 * g + 4 * u);
-                gf[t][u] = ok ? *(const f32x4 *)(p.dctx + trow[t] * C + head * 32 + 8 * g + 4 * u) : z;   // cropped outputs: dO = 0
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qf[t][u][e] = qv[e] * scale;
+                for (int e = 0; e < 4; ++e) qf[t][u][e] = qv2[u][e] * scale;
                 if (j < L) {
                     *(f32x4 *)(Ks + j * RS + 8 * g + 4 * u) = kf[t][u];
                     *(f32x4 *)(Ql + j * RS + 8 * g + 4 * u) = qf[t][u];
@@ -877,7 +930,12 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
                         int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
                         my += my < 0 ? p.Hp : 0;
                         mx += mx < 0 ? p.Wp : 0;
-                        kb = (my < p.H && mx < p.W) ? p.xf[(img + (long long)my * p.W + mx) * C] : 0.f;
+                        if (my < p.H && mx < p.W) {
+                            const long long mi = (img + (long long)my * p.W + mx) * C;
+                            kb = p.xf16 ? __uint_as_float((unsigned)p.xf16[mi] << 16) : p.xf[mi];
+                        } else {
+                            kb = 0.f;
+                        }
                     }
                 }
             }
@@ -966,10 +1024,13 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt)
             if (tok[qt]) {
-                float *dst = p.dqkv + trow[qt] * 3 * C + head * 32 + 4 * g;
+                const long long doff = trow[qt] * 3 * C + head * 32 + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    *(f32x4 *)(dst + 16 * dt) = f32x4{dq[qt][dt][0] * scale, dq[qt][dt][1] * scale, dq[qt][dt][2] * scale, dq[qt][dt][3] * scale};
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4 v = f32x4{dq[qt][dt][0] * scale, dq[qt][dt][1] * scale, dq[qt][dt][2] * scale, dq[qt][dt][3] * scale};
+                    if (p.dqkv16) store4_bf16(p.dqkv16 + doff + 16 * dt, v);
+                    else *(f32x4 *)(p.dqkv + doff + 16 * dt) = v;
+                }
             }
     }
     // ---- row orientation: S[q][k], dP[q][k]  ->  P, dS  ->  dK, dV -----------------------------------------------------
@@ -1055,11 +1116,16 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
         if (tok[kt]) {
-            float *dst = p.dqkv + trow[kt] * 3 * C + head * 32 + 4 * g;
+            const long long doff = trow[kt] * 3 * C + head * 32 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                *(f32x4 *)(dst + C + 16 * dt) = dk[kt][dt];
-                *(f32x4 *)(dst + 2 * C + 16 * dt) = dv[kt][dt];
+                if (p.dqkv16) {
+                    store4_bf16(p.dqkv16 + doff + C + 16 * dt, dk[kt][dt]);
+                    store4_bf16(p.dqkv16 + doff + 2 * C + 16 * dt, dv[kt][dt]);
+                } else {
+                    *(f32x4 *)(p.dqkv + doff + C + 16 * dt) = dk[kt][dt];
+                    *(f32x4 *)(p.dqkv + doff + 2 * C + 16 * dt) = dv[kt][dt];
+                }
             }
         } else if (tpad[kt]) {                    // k, v of a zero-padded token are the in-proj bias: their gradients belong to it
             padded = true;
@@ -1086,14 +1152,18 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
     }
 }
 
-// dbias_pad [3C]: zeros for the q third; for head h and j < 64 (k dims, then v dims) the sum over the (sample, window) pairs of
-// pad_parts[((pair) * heads + h) * 64 + j] -- sixteen contiguous ranges of pairs summed in order, then added in range order.
-__global__ __launch_bounds__(1024) void attn_pad_finish_kernel(const float *__restrict__ parts, long long pairs, int heads, int C, float *__restrict__ dbias_pad)
+// dbias_pad [3C] in two fixed-order steps.  Step 1 (grid heads x kPadRanges): block (h, r) adds the waves' (dk | dv) sums of head h over
+// its contiguous range r of (sample, window) pairs -- sixteen sub-ranges in pair order, then the sixteen sub-sums in order -- into
+// mid[(h * kPadRanges + r) * 64 + j].  Step 2 (one block per head): the ranges in order; the q third of the bias gets zeros.
+constexpr int kPadRanges = 64;
+__global__ __launch_bounds__(1024) void attn_pad_partial_kernel(const float *__restrict__ parts, long long pairs, int heads, float *__restrict__ mid)
 {
     __shared__ float sh[16][64];
-    const int h = blockIdx.x, j = threadIdx.x & 63, r = threadIdx.x >> 6;
-    const long long per = (pairs + 15) / 16;
-    const long long w0 = r * per, w1 = w0 + per < pairs ? w0 + per : pairs;
+    const int h = blockIdx.x, rg = blockIdx.y, j = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const long long per_blk = (pairs + kPadRanges - 1) / kPadRanges;
+    const long long b0 = rg * per_blk, b1 = b0 + per_blk < pairs ? b0 + per_blk : pairs;
+    const long long per = (per_blk + 15) / 16;
+    const long long w0 = b0 + r * per, w1 = w0 + per < b1 ? w0 + per : b1;
     float s = 0.f;
     for (long long w = w0; w < w1; ++w) s += parts[(w * heads + h) * 64 + j];
     sh[r][j] = s;
@@ -1102,9 +1172,17 @@ __global__ __launch_bounds__(1024) void attn_pad_finish_kernel(const float *__re
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sh[k][j];
-        dbias_pad[(j < 32 ? C : 2 * C) + h * 32 + (j & 31)] = t;
-        if (j < 32) dbias_pad[h * 32 + j] = 0.f;
+        mid[((long long)h * kPadRanges + rg) * 64 + j] = t;
     }
+}
+
+__global__ __launch_bounds__(64) void attn_pad_finish_kernel(const float *__restrict__ mid, int C, float *__restrict__ dbias_pad)
+{
+    const int h = blockIdx.x, j = threadIdx.x;
+    float t = 0.f;
+    for (int rg = 0; rg < kPadRanges; ++rg) t += mid[((long long)h * kPadRanges + rg) * 64 + j];
+    dbias_pad[(j < 32 ? C : 2 * C) + h * 32 + (j & 31)] = t;
+    if (j < 32) dbias_pad[h * 32 + j] = 0.f;
 }
 
 }  // namespace
@@ -1357,14 +1435,19 @@ extern "C" int ldm_window_attention_bwd_mfma(int v)
     return old;
 }
 
-extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
-                                            float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream)
+static int attention_bwd_impl(const char *who, const void *qkv, const float *in_proj_bias, const void *xf, const void *dctx, void *dqkv, float *dbias_pad,
+                              int B, int H, int W, int C, int ws, int shift, bool io16, void *stream)
 {
-    LDM_REQUIRE(qkv && in_proj_bias && dctx && dqkv && dbias_pad, "ldm_window_attention_bwd_f32: null pointer");
-    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0 && ws >= 1 && ws <= 6 && shift >= 0 && shift < ws,
-                "ldm_window_attention_bwd_f32: bad shape (window_size <= 6)");
+    LDM_REQUIRE(qkv && in_proj_bias && dctx && dqkv && dbias_pad, "%s: null pointer", who);
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0 && ws >= 1 && ws <= 6 && shift >= 0 && shift < ws, "%s: bad shape (window_size <= 6)", who);
     AttnB p{};
-    p.qkv = qkv; p.bias = in_proj_bias; p.xf = xf; p.dctx = dctx; p.dqkv = dqkv; p.dbias_pad = dbias_pad;
+    p.bias = in_proj_bias; p.dbias_pad = dbias_pad;
+    if (io16) {
+        p.qkv16 = (const unsigned short *)qkv; p.dctx16 = (const unsigned short *)dctx; p.xf16 = (const unsigned short *)xf; p.dqkv16 = (unsigned short *)dqkv;
+        LDM_REQUIRE(ldm_aligned16(qkv) && ldm_aligned16(dctx) && (((size_t)dqkv) & 7) == 0, "%s: unaligned bf16 rows", who);
+    } else {
+        p.qkv = (const float *)qkv; p.dctx = (const float *)dctx; p.xf = (const float *)xf; p.dqkv = (float *)dqkv;
+    }
     p.B = B; p.H = H; p.W = W; p.C = C; p.ws = ws; p.shift = shift; p.heads = C / 32;
     p.global = (H <= ws && W <= ws) ? 1 : 0;
     if (p.global) {
@@ -1372,14 +1455,15 @@ extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_pr
     } else {
         p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
         p.nwh = p.Hp / ws; p.nww = p.Wp / ws; p.L = ws * ws;
-        LDM_REQUIRE(shift == 0 || xf != nullptr, "ldm_window_attention_bwd_f32: shift != 0 needs xf");
+        LDM_REQUIRE(shift == 0 || xf != nullptr, "%s: shift != 0 needs xf", who);
     }
     p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
     hipStream_t st = (hipStream_t)stream;
-    p.pad_parts = (float *)ldm_scratch(st, (size_t)p.total_waves * 64 * sizeof(float));
+    p.pad_parts = (float *)ldm_scratch(st, ((size_t)p.total_waves + (size_t)p.heads * kPadRanges) * 64 * sizeof(float));
     if (!p.pad_parts) return LDM_ELAUNCH;
+    float *pad_mid = p.pad_parts + (size_t)p.total_waves * 64;
     const dim3 grid((unsigned)((p.total_waves + 1) / 2));
-    if (g_attn_bwd_mfma) {                              // every window the reference builds has L <= 36
+    if (g_attn_bwd_mfma || io16) {                      // every window the reference builds has L <= 36
         const int nt = (p.L + 15) / 16;
         const size_t smem = 2ull * (3 * p.L * 36 + 16 * nt) * sizeof(float);
         if (nt == 1) hipLaunchKernelGGL(window_attention_bwd_mfma_kernel<1>, grid, dim3(128), smem, st, p);
@@ -1390,7 +1474,20 @@ extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_pr
         const size_t smem = 2ull * (2 * LMAX * 36 + 2 * LMAX * (LMAX + 1) + LMAX + 4) * sizeof(float);
         hipLaunchKernelGGL(window_attention_bwd_kernel<LMAX>, grid, dim3(128), smem, st, p);
     }
-    hipLaunchKernelGGL(attn_pad_finish_kernel, dim3(p.heads), dim3(1024), 0, st, (const float *)p.pad_parts, p.total_waves / p.heads, p.heads, C, dbias_pad);
-    LDM_CHECK_LAUNCH("ldm_window_attention_bwd_f32");
+    hipLaunchKernelGGL(attn_pad_partial_kernel, dim3(p.heads, kPadRanges), dim3(1024), 0, st, (const float *)p.pad_parts, p.total_waves / p.heads, p.heads, pad_mid);
+    hipLaunchKernelGGL(attn_pad_finish_kernel, dim3(p.heads), dim3(64), 0, st, (const float *)pad_mid, C, dbias_pad);
+    LDM_CHECK_LAUNCH(who);
     return LDM_OK;
+}
+
+extern "C" int ldm_window_attention_bwd_f32(const float *qkv, const float *in_proj_bias, const float *xf, const float *dctx, float *dqkv,
+                                            float *dbias_pad, int B, int H, int W, int C, int ws, int shift, void *stream)
+{
+    return attention_bwd_impl("ldm_window_attention_bwd_f32", qkv, in_proj_bias, xf, dctx, dqkv, dbias_pad, B, H, W, C, ws, shift, false, stream);
+}
+
+extern "C" int ldm_window_attention_bwd_bf16(const void *qkv, const float *in_proj_bias, const void *xf, const void *dctx, void *dqkv, float *dbias_pad,
+                                             int B, int H, int W, int C, int ws, int shift, void *stream)
+{
+    return attention_bwd_impl("ldm_window_attention_bwd_bf16", qkv, in_proj_bias, xf, dctx, dqkv, dbias_pad, B, H, W, C, ws, shift, true, stream);
 }

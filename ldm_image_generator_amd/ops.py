@@ -611,3 +611,22 @@ def up2_add(coarse, skip, out, B, H, W, C):
 def avgpool2_bf16(x, out16, B, H, W, C):
     _call("ldm_avgpool2_bf16", _dev(x, "x"), _dev(out16, "out", BF16), B, H, W, C)
     return out16
+
+
+def window_attention_bwd_bf16(qkv16, in_proj_bias, xf16, dctx16, dqkv16, dbias_pad, B, H, W, C, ws, shift):
+    """window_attention_bwd with bf16 rows in (qkv, float-mask source, dctx) and bf16 dqkv out; dbias_pad fp32 [3C]."""
+    _call("ldm_window_attention_bwd_bf16", _dev(qkv16, "qkv", BF16), _dev(in_proj_bias, "bias"), _opt(xf16, "xf", BF16), _dev(dctx16, "dctx", BF16),
+          _dev(dqkv16, "dqkv", BF16), _dev(dbias_pad, "dbias_pad"), B, H, W, C, ws, shift)
+
+
+def gconv_pack_bf16(w, fwd16, rot16):
+    """conv.weight [C, 32, 3, 3] fp32 -> the grouped conv's bf16 filter tables: forward [C, 288] and data-gradient (flipped, in/out swapped) [C, 288]."""
+    _call("ldm_gconv_pack_bf16", _dev(w, "w"), _dev(fwd16, "fwd", BF16), _dev(rot16, "rot", BF16), w.shape[0])
+
+
+def replicate(src, reps):
+    """-> [reps, n] fp32: ``reps`` separate copies of the vector ``src`` in one launch."""
+    n = src.numel()
+    out = torch.empty(reps, n, device=src.device, dtype=torch.float32)
+    _call("ldm_replicate_f32", _dev(src, "src"), _dev(out, "out"), n, reps)
+    return out

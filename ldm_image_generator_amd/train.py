@@ -435,7 +435,29 @@ class _Weight16:
             self.keep = plist
         _lib.check(lib.ldm_multi_cast_bf16(self.items, len(plist), self.table.data_ptr(), int(rebuild), ctypes.byref(self.tiles),
                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ldm_multi_cast_bf16")
+        # the grouped conv's two bf16 filter tables (forward, data gradient) of every block: one launch per block
+        if rebuild:
+            self.conv = {}
+        for blk in [b for l in net.encoder_stages for b in l.stage.blocks] + [b for l in net.decoder_stages for b in l.stage.blocks]:
+            w = blk.conv.weight
+            hit = self.conv.get(id(blk))
+            if hit is None or hit[0] != w.data_ptr():
+                c = w.shape[0]
+                hit = self.conv[id(blk)] = (w.data_ptr(), _e16(c, 288, dev=w.device), _e16(c, 288, dev=w.device))
+            ops.gconv_pack_bf16(w.detach(), hit[1], hit[2])
         self.net_id, self.stamp = id(net), stamp
+
+    def conv_tables(self, blk):
+        """(forward, data-gradient) bf16 filter tables of ``blk``'s grouped conv: from the step's refresh, or built on the spot
+        for a block outside the refreshed network."""
+        hit = getattr(self, "conv", {}).get(id(blk))
+        w = blk.conv.weight
+        if hit is not None and hit[0] == w.data_ptr():
+            return hit[1], hit[2]
+        c = w.shape[0]
+        fwd, rot = _e16(c, 288, dev=w.device), _e16(c, 288, dev=w.device)
+        ops.gconv_pack_bf16(w.detach().contiguous(), fwd, rot)
+        return fwd, rot
 
     def get(self, p, transposed=False):
         hit = self.views.get(id(p))
@@ -512,21 +534,21 @@ def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
     b, h, w = shape
     m, c = rows.shape
     dev = rows.device
-    # the fp32 copy of the normalised input is only read by window attention (its float "mask" and the fp32 attention kernels)
-    xf = torch.empty_like(rows) if blk.attention_flag else None
+    # window attention reads the bf16 copy too (q, k, v rows and the float "mask" of shifted windows): no fp32 copy is kept
+    xf = None
     xf16 = _e16(m, c, dev=dev)
-    ops.channelnorm_film_bf16(rows, film, ctx.slot, xf, xf16, b, h * w, c, blk.norm.eps)
+    ops.channelnorm_film_bf16(rows, film, ctx.slot, None, xf16, b, h * w, c, blk.norm.eps)
     y = torch.empty_like(rows)
-    ops.gconv3x3_bf16(xf16, ops.cast_bf16(blk._conv_weight()), blk.conv.bias.detach(), rows, y, b, h, w, c)
+    ops.gconv3x3_bf16(xf16, W16.conv_tables(blk)[0], blk.conv.bias.detach(), rows, y, b, h, w, c)
     sv = dict(blk=blk, x=rows, xf=xf, xf16=xf16, film=film, codes=codes16, enc_hidden=enc_hidden16, picks=picks, shape=shape)
     if blk.attention_flag:
         att = blk.self_attention.attention
-        qkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
+        # q, k, v and the attention context travel as bf16 rows (half the bytes each way); the attention arithmetic itself is fp32
+        qkv = _e16(m, 3 * c, dev=dev)
         ops.gemm_bf16(xf16, m, 3 * c, c, [W16.get(att.in_proj_weight)], qkv, biases=[att.in_proj_bias.detach()])
-        actx = torch.empty(m, c, device=dev, dtype=torch.float32)
-        ops.window_attention(qkv, att.in_proj_bias.detach(), xf, actx, b, h, w, c, blk.self_attention.window_size,
-                             blk.self_attention.shift)
-        actx16 = ops.cast_bf16(actx)
+        actx16 = _e16(m, c, dev=dev)
+        ops.window_attention_bf16io(qkv, att.in_proj_bias.detach(), xf16, actx16, b, h, w, c, blk.self_attention.window_size,
+                                    blk.self_attention.shift)
         ops.gemm_bf16(actx16, m, c, c, [W16.get(att.out_proj.weight)], y, biases=[att.out_proj.bias.detach()], addend=y)
         sv.update(qkv=qkv, actx16=actx16)
     regs = [blk.ffn.general] + [blk.ffn.experts[i] for i in picks]
@@ -559,9 +581,12 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     ops.gemm_bf16(db, m, c, 3 * f, [W16.get(r.b.weight, True) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)
     dwa, dba = grad_weight_rows16(da, xf16, m)                        # [3F, C]
     dwb, dbb = grad_weight_rows16(db, xf16, m)
+    # the column sums of dy are the gradient of every bias added to y: three c-biases, the conv bias, the out-projection bias --
+    # separate rows (one launch) so that no two parameters share gradient storage
+    brows = ops.replicate(bias_dy, 4 + int(blk.attention_flag))
     for e, r in enumerate(regs):
         grads.add(r.c.weight, dwc[:, e * f:(e + 1) * f])
-        grads.add(r.c.bias, bias_dy.clone())
+        grads.add(r.c.bias, brows[e])
         grads.add(r.a.weight, dwa[e * f:(e + 1) * f])
         grads.add(r.b.weight, dwb[e * f:(e + 1) * f])
         grads.add(r.a.bias, dba[e * f:(e + 1) * f])
@@ -569,22 +594,21 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     # ---- window attention ---------------------------------------------------------------------------
     if blk.attention_flag:
         att = blk.self_attention.attention
-        dctx = torch.empty(m, c, device=dev, dtype=torch.float32)
+        dctx = _e16(m, c, dev=dev)
         ops.gemm_bf16(dy16, m, c, c, [W16.get(att.out_proj.weight, True)], dctx)
         dwo, _ = grad_weight_rows16(dy16, sv["actx16"], m, want_colsum=False)
         grads.add(att.out_proj.weight, dwo)
-        grads.add(att.out_proj.bias, bias_dy.clone())
-        dqkv = torch.empty(m, 3 * c, device=dev, dtype=torch.float32)
+        grads.add(att.out_proj.bias, brows[4])
+        dqkv16 = _e16(m, 3 * c, dev=dev)
         dpad = torch.empty(3 * c, device=dev, dtype=torch.float32)
-        ops.window_attention_bwd(sv["qkv"], att.in_proj_bias.detach(), xf, dctx, dqkv, dpad, b, h, w, c,
-                                 blk.self_attention.window_size, blk.self_attention.shift)
-        dqkv16 = ops.cast_bf16(dqkv)
+        ops.window_attention_bwd_bf16(sv["qkv"], att.in_proj_bias.detach(), xf16, dctx, dqkv16, dpad, b, h, w, c,
+                                      blk.self_attention.window_size, blk.self_attention.shift)
         ops.gemm_bf16(dqkv16, m, c, 3 * c, [W16.get(att.in_proj_weight, True)], dxf, addend=dxf)
         dwi, dbi = grad_weight_rows16(dqkv16, xf16, m)
         grads.add(att.in_proj_weight, dwi)
         grads.add(att.in_proj_bias, ops.add_(dbi.clone(), dpad))
     # ---- grouped 3x3 conv: data gradient on the bf16 matrix cores, weight gradient by the fp32 kernel ----------
-    _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=dy16, xf16=xf16)
+    _gconv_backward(blk, xf, dy, dxf, brows[3], shape, grads, dy16=dy16, xf16=xf16)
     # ---- ChannelNorm + FiLM, residual ---------------------------------------------------------------------
     film = sv["film"]
     dfilm16 = _e16(film.shape[0], film.shape[1], dev=dev)
@@ -603,14 +627,14 @@ def _gconv_backward(blk, xf, dy, dxf, bias_dy, shape, grads, dy16=None, xf16=Non
     dev = dy.device
     g = c // 32
     wconv = blk.conv.weight.detach()                               # [C, 32, 3, 3] = [g, co, ci, ky, kx]
-    wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
     if dy16 is not None:
-        ops.gconv3x3_bf16(dy16, ops.cast_bf16(wrot), None, dxf, dxf, b, h, w, c)
+        ops.gconv3x3_bf16(dy16, W16.conv_tables(blk)[1], None, dxf, dxf, b, h, w, c)
         dwconv = ops.gconv3x3_wgrad_bf16(xf16, dy16, b, h, w, c)
         grads.add(blk.conv.weight, dwconv.reshape(c, 3, 3, 32).permute(0, 3, 1, 2))
-        grads.add(blk.conv.bias, bias_dy.clone())
+        grads.add(blk.conv.bias, bias_dy)                          # the caller's own row of the replicated column sums
         return
     else:
+        wrot = wconv.reshape(g, 32, 32, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(c, 288).contiguous()
         ops.gemm(dy, m, 32, 288, [wrot], dxf, lda=c, ldw=288, addend=dxf, ldadd=c, ldo=c, a_mode=ops.A_CONV3X3, conv_hw=(h, w),
                  cin=32, groups=g, a_gstride=32, w_gstride=32 * 288, o_gstride=32, b_gstride=32)
     dwconv = torch.empty(g, 32, 288, device=dev, dtype=torch.float32)

@@ -38,8 +38,10 @@ ops.prof_enable(True)
 t0 = time.perf_counter()
 for i in range(args.steps):
     loss = ldist.train_step(ddpm, opt, x, 1 + i, 1)
+host = (time.perf_counter() - t0) / args.steps          # time the host needed to ENQUEUE a step (no synchronisation inside a step)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
+print("host enqueue %.1f ms/step of %.1f ms/step" % (host * 1e3, dt * 1e3))
 n, ms, fl = ops.prof_read()
 ops.prof_enable(False)
 print("batch %d latent %d: %.1f ms/step, %.1f samples/s, loss %.4f | GEMM launches/step %d, GEMM %.1f ms/step at %.1f TFLOP/s, peak mem %.1f GB"
