@@ -92,7 +92,7 @@ def gpu_vs_cpu(gpu, cpu):
 
 def traffic_table():
     """PMC-derived HBM traffic of the GEMM family (separate rocprofv3 --pmc passes: tools/traffic_summary.py); newest round first."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             return name, json.load(open(path))
@@ -119,6 +119,10 @@ def main():
     ap.add_argument("--no-autocast-leg", action="store_true", help="skip the secondary measurement in the opt-in bf16 (autocast) mode")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the secondary measurement under GEMM schedule 2 (bf16x3 split consumer)")
+    ap.add_argument("--no-vae-train-leg", action="store_true", help="skip the VAE training iteration (SURVEY 8 f4: train_vae.py's loop body)")
+    ap.add_argument("--vae-batch", type=int, default=8)
+    ap.add_argument("--vae-size", type=int, default=256)
+    ap.add_argument("--vae-steps", type=int, default=3)
     ap.add_argument("--no-train-step-leg", action="store_true", help="skip the training-step measurement (BASELINE cfg 5 per-GPU shape)")
     ap.add_argument("--train-batch", type=int, default=128, help="training-step leg: samples per GPU (cfg 5: 1024 / 8)")
     ap.add_argument("--train-latent", type=int, default=64, help="training-step leg: latent edge (512 px / 8)")
@@ -426,6 +430,74 @@ def main():
         del opt, xb
         net.train(args.mode == "train")
 
+    # one iteration of train_vae.py's loop (train_vae.py:104-127) -- VAE objective (L1 reconstruction x 10 + VQ loss +
+    # 0.1 x generator hinge through the Discriminator) backward + optimizer, then the Discriminator's own hinge step -- on synthetic
+    # 256x256 images, batch 8 (the script's defaults are batch 1, 192x192 crops), exact fp32.  torch.optim.AdamW(fused=True) stands in
+    # for transformers' Adafactor (not on the hot path; `transformers` optimizers are out of scope).
+    vae_step = None
+    if not args.no_vae_train_leg:
+        from ldm_image_generator_amd.vae import VAE, Discriminator, Encoder, VectorQuantizer
+        torch.cuda.empty_cache()
+        enc_v, dec_v, disc_v = Encoder(), Decoder(), Discriminator()
+        for m_ in (enc_v, dec_v, disc_v):
+            m_.load_state_dict(synth.fill_state_dict(m_.state_dict()))
+        torch.manual_seed(1234)
+        vq_v = VectorQuantizer()
+        vae_v = VAE(enc_v, dec_v, vq_v).to(dev)
+        disc_v = disc_v.to(dev)
+        opt_v = torch.optim.AdamW(vae_v.parameters(), lr=1e-4, fused=True)
+        opt_dv = torch.optim.AdamW(disc_v.parameters(), lr=1e-4, fused=True)
+        vb, vs = args.vae_batch, args.vae_size
+        img_v = (torch.rand(vb, 3, vs, vs, generator=torch.Generator().manual_seed(7 + rank)) * 2 - 1).to(dev)
+
+        def vae_iter():
+            opt_v.zero_grad()
+            recon, reg, y = vae_v.calclate_loss(img_v)
+            adv = torch.relu(-disc_v.calclate_logit(y)).mean()
+            (recon * 10.0 + reg * 1.0 + adv * 0.1).backward()
+            opt_v.step()
+            opt_dv.zero_grad()
+            y = y.detach()
+            d_loss = torch.relu(1 + disc_v.calclate_logit(y)).mean() + torch.relu(1 - disc_v.calclate_logit(img_v)).mean()
+            d_loss.backward()
+            opt_dv.step()
+            return recon, reg, adv, d_loss
+
+        for _ in range(2):
+            vae_iter()
+        fence()
+        ops.prof_enable(rank == 0)
+        t0 = time.perf_counter()
+        for _ in range(args.vae_steps):
+            losses = vae_iter()
+        fence()
+        dtv = max_over_ranks(time.perf_counter() - t0)
+        vae_step = {"ms_per_step": dtv / args.vae_steps * 1e3, "value": vb * world * args.vae_steps / dtv, "unit": "images/s", "dtype": "f32",
+                    "config": {"workload": "train_vae.py iteration: VAE loss + generator hinge backward + AdamW, then Discriminator hinge step + AdamW; "
+                                           "images [%d, 3, %d, %d] per GPU, Encoder / Decoder / VectorQuantizer(8192 x 8) / Discriminator at default widths" % (vb, vs, vs),
+                               "steps": args.vae_steps, "warmup": 2},
+                    "losses": {"recon": float(losses[0]), "reg": float(losses[1]), "adv": float(losses[2]), "disc": float(losses[3])},
+                    "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+        if rank == 0:
+            per, tot_ms, tot_fl, tot_by = {}, 0.0, 0.0, 0.0
+            for cls, name in PROF_CLASSES.items():
+                n, ms, fl = ops.prof_read_class(cls)
+                if n:
+                    by = ops.prof_read_bytes(cls)
+                    per[name] = {"launches_per_step": n // args.vae_steps, "ms_per_step": ms / args.vae_steps, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None}
+                    tot_ms, tot_fl, tot_by = tot_ms + ms, tot_fl + fl, tot_by + by
+            ops.prof_read()
+            if tot_ms > 0:
+                ach = tot_fl / (tot_ms * 1e-3) / 1e12
+                vae_step["executed_gflop_per_step"] = tot_fl / 1e9 / args.vae_steps
+                vae_step["mfma_kernel_ms_per_step"] = tot_ms / args.vae_steps
+                vae_step["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                                        "kernel": "all MFMA kernels of the iteration (implicit 3x3 NT GEMMs, TN / NT weight-gradient GEMMs), hipEvents per launch",
+                                        "per_kernel": per}
+        ops.prof_enable(False)
+        del vae_v, disc_v, opt_v, opt_dv, img_v
+        torch.cuda.empty_cache()
+
     if rank == 0:
         images = gb * args.steps
         ms_per_step = dt / args.steps * 1e3
@@ -477,6 +549,8 @@ def main():
             line["train_step"] = train_step
         if cfg2 is not None:
             line["cfg2"] = cfg2
+        if vae_step is not None:
+            line["vae_train_step"] = vae_step
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"], cpu_out = cpu_baseline(min(os.cpu_count() or 1, 64))
             line["cpu_baseline"]["gpu_vs_cpu_rel_l2"] = gpu_vs_cpu(probe, cpu_out)
