@@ -9,8 +9,11 @@ and (N > 1) the single all-gather of the images (BASELINE.json configs[2]/[3]). 
 already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 Secondary objects on the same line (never `value`): `train_mode` (the reference-faithful sampling mode),
-`split_schedule` (GEMM schedule 2), `train_step` (BASELINE.json configs[4]: one optimisation step of train_ldm.py on
-latents [128, 8, 64, 64] per GPU, AdamW included, fp32 and bf16 operands), `cpu_baseline`.
+`split_schedule` (GEMM schedule 2), `autocast_bf16` (the opt-in bf16 sampling + decode mode: ddpm.py:52,75), `cfg2` (BASELINE.json
+configs[1]: pixel-space 64x64, batch 64, UNet only), `train_step` (BASELINE.json configs[4]: one optimisation step of train_ldm.py on
+latents [128, 8, 64, 64] per GPU, AdamW included, fp32 and bf16 operands; for N > 1 with the bucketed, overlapped gradient all-reduce),
+`vae_train_step` (one iteration of train_vae.py's loop), `cpu_baseline` (with `gpu_vs_cpu_rel_l2`: the HIP path checked
+against the oracle outputs of the baseline's own timed sample), and at N = 1 `slices_check` (4 rows of the timed batch re-run alone).
 """
 import argparse
 import json
