@@ -415,6 +415,10 @@ int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, i
  * (scores, softmax, P.V) is fp32.  ws*ws <= 48. */
 int ldm_window_attention_bf16io(const void *qkv, int qkv_is_bf16, const float *in_proj_bias, const void *xf_bf16, void *out_bf16,
                                 int B, int H, int W, int C, int ws, int shift, void *stream);
+/* core of ldm_window_attention_bf16io when qkv is bf16: 1 (default) = both products on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16 for
+ * K Q^T over the 32 head dims, v_mfma_f32_16x16x16_bf16 for P V with P rounded once to bf16; scores, softmax in fp32), 0 = the fp32
+ * 16x16x4 core on the widened values (A/B tests).  Returns the previous setting; any other v only queries. */
+int ldm_window_attention_bf16_core(int v);
 /* ldm_stem_nchw_f32 with bf16 rows out (VAE Decoder.input_layer, vae.py:112,123) */
 int ldm_stem_nchw_bf16(const float *x, const float *w, const float *bias, void *out_bf16, int B, int Cin, int HW, int C0, void *stream);
 /* the scatter of ConvTranspose2d(k=2, s=2) (vae.py:120) as its own pass: in [B*H*W, 4*C] bf16 with columns (dy, dx, c)

@@ -178,6 +178,7 @@ SIGNATURES = {
     "ldm_film_hidden_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     # bf16 sampling / decode
     "ldm_window_attention_bf16io": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_window_attention_bf16_core": (_I, [_I]),
     "ldm_stem_nchw_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_depth_to_space2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_rgb_head_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

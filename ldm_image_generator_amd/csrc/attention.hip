@@ -12,6 +12,8 @@
 
 namespace {
 
+int g_attn_bf16_core = 1;        // ldm_window_attention_bf16io with bf16 QKV: 1 = bf16 matrix cores (default), 0 = the fp32 16x16x4 core (A/B tests)
+
 struct AttnP {
     const float *qkv, *bias, *xf;
     float *out;
@@ -369,6 +371,185 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const AttnP 
         }
 }
 
+
+// ---- bf16 matrix-core version (bf16 QKV rows in, bf16 context out): the autocast sampling mode and the bf16 training step --------------
+// Same work split (one wave per sample x window x head) and the same index arithmetic; the two products run on the bf16 matrix cores:
+//   S^T = K Q^T   ONE v_mfma_f32_16x16x32_bf16 per 16 x 16 tile: the head dimension (32) is the instruction's K, and a lane's operand
+//                 -- row c of the tile, dims [8 g, 8 g + 8) -- is one 16-byte load of the token's bf16 row; scores accumulate in fp32,
+//                 scale and key bias are applied in fp32, softmax in fp32 (v_exp_f32);
+//   O^T = V^T P^T v_mfma_f32_16x16x16_bf16: P^T (rounded once to bf16, as every 16-bit attention does) is the B operand straight from
+//                 the score tile's registers (keys 16 kt + 4 g + e of query column c); V^T comes from the wave's LDS image of V
+//                 ([key][32 dims] bf16, 80-byte rows) through the transposing read ds_read_b64_tr_b16 -- lane (d = lane & 15, g) receives
+//                 V[16 kt + 4 g + 0..3][16 dt + d], its A operand.
+// 27 matrix instructions of 8-16 cycles instead of 144 of 32: the fp32 16x16x4 core above is matrix-pipe-bound (MFMA busy 0.32 of a
+// latency-bound kernel); this one is bound by its loads and the 36 exponentials per lane.
+typedef short bfrag8 __attribute__((ext_vector_type(8)));
+typedef short bfrag4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2a __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) bfrag4 *lds_bfrag4_ptr;
+
+__device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi)
+{
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const f32x2v v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+
+// eight consecutive values of the bias, rounded to bf16 (a zero-padded token's q / k / v as the bf16 projection stores them)
+__device__ __forceinline__ u32x4a bias8_bf16(const float *b)
+{
+    const f32x4 b0 = *(const f32x4 *)b, b1 = *(const f32x4 *)(b + 4);
+    return u32x4a{pack_bf16_pair(b0[0], b0[1]), pack_bf16_pair(b0[2], b0[3]), pack_bf16_pair(b1[0], b1[1]), pack_bf16_pair(b1[2], b1[3])};
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void window_attention_bf16_kernel(const AttnP p)
+{
+    constexpr int LT = 16 * NT;
+    constexpr int VS = 80;                                   // bytes per V row in LDS (64 used)
+    constexpr int WB = LT * VS + LT * 4;                      // bytes per wave: V image, then the key bias
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int L = p.L, C = p.C;
+    unsigned char *Vs = smem16 + wave * WB;
+    float *Kb = (float *)(Vs + LT * VS);
+
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const bool active = gw < p.total_waves;
+    const int head = (int)(gw % p.heads);
+    const long long t1 = gw / p.heads;
+    const int nwin = p.global ? 1 : p.nwh * p.nww;
+    const int win = (int)(t1 % nwin);
+    const long long b = t1 / nwin;
+    const int wr = win / p.nww, wc = win - wr * p.nww;
+    const long long img = b * p.H * p.W;
+    const float scale = 0.17677669529663687f;                // sqrt(1/32)
+
+    u32x4a kf[NT], qf[NT];
+    long long orow[NT];
+    bool qok[NT];
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + c;
+            int sy = 0, sx = 0, py, px;
+            const bool ok = j < L && token_src(p, wr, wc, j, sy, sx, py, px);
+            const long long roff = (img + (long long)sy * p.W + sx) * 3 * C + head * 32 + 8 * g;
+            qok[t] = ok;
+            orow[t] = (img + (long long)sy * p.W + sx) * C + head * 32;
+            if (ok) {
+                qf[t] = *(const u32x4a *)(p.qkv16 + roff);
+                kf[t] = *(const u32x4a *)(p.qkv16 + roff + C);
+            } else {                                            // zero-padded token (or a token past L: any finite value, its key bias is -inf)
+                qf[t] = bias8_bf16(p.bias + head * 32 + 8 * g);
+                kf[t] = bias8_bf16(p.bias + C + head * 32 + 8 * g);
+            }
+        }
+        for (int idx = lane; idx < LT * 4; idx += 64) {
+            const int j = idx >> 2, ch = (idx & 3) * 8;
+            int sy = 0, sx = 0, py, px;
+            u32x4a vv{0u, 0u, 0u, 0u};
+            if (j < L) {
+                const bool ok = token_src(p, wr, wc, j, sy, sx, py, px);
+                vv = ok ? *(const u32x4a *)(p.qkv16 + (img + (long long)sy * p.W + sx) * 3 * C + 2 * C + head * 32 + ch)
+                        : bias8_bf16(p.bias + 2 * C + head * 32 + ch);
+            }
+            *(u32x4a *)(Vs + j * VS + ch * 2) = vv;
+        }
+        if (lane < LT) {
+            float kb = -INFINITY;
+            if (lane < L) {
+                int sy, sx, py, px;
+                const bool ok = token_src(p, wr, wc, lane, sy, sx, py, px);
+                kb = 0.f;
+                if (!p.global) {
+                    if (p.shift == 0) {
+                        kb = ok ? 0.f : -INFINITY;
+                    } else {
+                        int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
+                        my += my < 0 ? p.Hp : 0;
+                        mx += mx < 0 ? p.Wp : 0;
+                        kb = (my < p.H && mx < p.W) ? __uint_as_float((unsigned)p.xf16[(img + (long long)my * p.W + mx) * C] << 16) : 0.f;
+                    }
+                }
+            }
+            Kb[lane] = kb;
+        }
+    }
+    __syncthreads();
+    if (!active) return;                                     // whole waves only: the transposing reads below need a full EXEC mask
+
+    // ---- S^T = K Q^T, scale, key bias, softmax over the keys of each query column ---------------------------------------------
+    f32x4 s[NT][NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfrag8, kf[kt]), __builtin_bit_cast(bfrag8, qf[qt]),
+                                                                f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    float kbv[NT][4];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kbv[kt][e] = Kb[16 * kt + 4 * g + e];
+    bfrag4 pb[NT][NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[kt][qt][e] = s[kt][qt][e] * scale + kbv[kt][e];
+                mx = fmaxf(mx, s[kt][qt][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[kt][qt][e] = __expf(s[kt][qt][e] - mx);
+                sum += s[kt][qt][e];
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const u32x2a w = {pack_bf16_pair(s[kt][qt][0] * inv, s[kt][qt][1] * inv), pack_bf16_pair(s[kt][qt][2] * inv, s[kt][qt][3] * inv)};
+            pb[kt][qt] = __builtin_bit_cast(bfrag4, w);
+        }
+    }
+
+    // ---- O^T = V^T P^T ----------------------------------------------------------------------------------------------------
+    f32x4 o[NT][2];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) o[qt][0] = o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = c >> 2, tp = c & 3;                        // this lane SUPPLIES row tq, columns 4 tp .. 4 tp + 3 of its group's 4 x 16 block
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const unsigned char *src = Vs + (16 * kt + 4 * g + tq) * VS + (16 * dt + 4 * tp) * 2;
+            const bfrag4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bfrag4_ptr)src);
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb[kt][qt], o[qt][dt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+        if (qok[qt]) {                                        // padded queries are cropped (attention.py:59)
+            unsigned short *dst = p.out16 + orow[qt] + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                *(u32x2a *)(dst + 16 * dt) = u32x2a{pack_bf16_pair(o[qt][dt][0], o[qt][dt][1]), pack_bf16_pair(o[qt][dt][2], o[qt][dt][3])};
+        }
+}
+
 }  // namespace
 
 static int window_attention_impl(const float *qkv, const float *in_proj_bias, const float *xf, const void *xf16, float *out, void *out16, int B, int H,
@@ -378,6 +559,13 @@ extern "C" int ldm_window_attention_f32(const float *qkv, const float *in_proj_b
                                         int W, int C, int ws, int shift, void *stream)
 {
     return window_attention_impl(qkv, in_proj_bias, xf, nullptr, out, nullptr, B, H, W, C, ws, shift, stream);
+}
+
+extern "C" int ldm_window_attention_bf16_core(int v)
+{
+    const int old = g_attn_bf16_core;
+    if (v == 0 || v == 1) g_attn_bf16_core = v;
+    return old;
 }
 
 extern "C" int ldm_window_attention_bf16io(const void *qkv, int qkv_is_bf16, const float *in_proj_bias, const void *xf_bf16, void *out_bf16, int B, int H,
@@ -413,6 +601,16 @@ static int window_attention_impl(const float *qkv, const float *in_proj_bias, co
     p.total_waves = (long long)B * p.nwh * p.nww * p.heads;
     const unsigned blocks = (unsigned)((p.total_waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
+    if (qkv16 && out16 && p.L <= 48 && (p.global || p.shift == 0 || xf16) && g_attn_bf16_core) {        // bf16 rows in and out: the bf16 matrix cores
+        LDM_REQUIRE(ldm_aligned16(qkv) && C % 8 == 0, "ldm_window_attention_bf16io: bf16 QKV rows must be 16-byte addressable");
+        const int nt = (p.L + 15) / 16;
+        const size_t smem = 4ull * (16 * nt * 80 + 16 * nt * 4);
+        if (nt == 1) hipLaunchKernelGGL(window_attention_bf16_kernel<1>, dim3(blocks), dim3(256), smem, st, p);
+        else if (nt == 2) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(blocks), dim3(256), smem, st, p);
+        else hipLaunchKernelGGL(window_attention_bf16_kernel<3>, dim3(blocks), dim3(256), smem, st, p);
+        LDM_CHECK_LAUNCH("ldm_window_attention_bf16io");
+        return LDM_OK;
+    }
     if (p.L <= 16) {
         hipLaunchKernelGGL(window_attention_mfma_kernel<1>, dim3(blocks), dim3(256), 4ull * (16 * 36 + 16) * sizeof(float), st, p);
     } else if (p.L <= 32) {

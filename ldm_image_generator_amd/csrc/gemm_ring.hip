@@ -500,9 +500,8 @@ int ring_shape(const GemmP &p, int groups, bool gate, bool out_bf16, bool fp32, 
     if (gate) return (unit % 128 == 0 && fills(mt * (p.N / 128))) ? 2 : 0;
     if (unit % 256 == 0 && fills(mt * (p.N / 256))) return 2;
     if (fp32 && unit % 128 == 0 && (any || !p.addend || p.K >= 384) && fills(mt * (p.N / 128))) return 1;
-    // bf16, fp32 output: 256 x 128 tiles where 256-column tiles leave CUs idle and the K loop is long enough to carry them (the c-GEMM /
-    // out-projection of the 8 x 8 level at batch 256: M = 16 384, N = 512 -- 128 tiles of 256 x 256 on 256 CUs ran on the stream kernel)
-    if (!fp32 && !out_bf16 && unit % 128 == 0 && (any || p.K >= 256) && fills(mt * (p.N / 128))) return 1;
+    // (bf16 has no 256 x 128 instance: a bf16 slice of such a tile is 4 MFMAs per wave, fewer than the 5 fragment reads the schedule pins
+    // behind them -- the K-segment GEMM of the 8 x 8 level at batch 256, 128 tiles of 256 x 256, stays on the stream kernel)
     return 0;
 }
 
@@ -519,9 +518,7 @@ extern "C" int ldm_gemm_ring(int v)
 int ldm_gemm_ring_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hipStream_t st)
 {
     if (p.act != LDM_ACT_NONE && p.act != LDM_ACT_RELU && p.act != LDM_ACT_LRELU) return 0;
-    const int nj = ring_shape(p, groups, false, out_bf16, false);
-    if (nj == 0) return 0;
-    if (nj == 1) return p.addend ? ring_launch<1, 1, false, false, true>(p, st) : ring_launch<1, 1, false, false, false>(p, st);
+    if (ring_shape(p, groups, false, out_bf16, false) != 2) return 0;
     if (out_bf16) return ring_launch<1, 2, false, true>(p, st);
     return p.addend ? ring_launch<1, 2, false, false, true>(p, st) : ring_launch<1, 2, false, false, false>(p, st);
 }

@@ -630,3 +630,8 @@ def replicate(src, reps):
     out = torch.empty(reps, n, device=src.device, dtype=torch.float32)
     _call("ldm_replicate_f32", _dev(src, "src"), _dev(out, "out"), n, reps)
     return out
+
+
+def window_attention_bf16_core(v):
+    """1 (default): bf16-QKV attention on the bf16 matrix cores; 0: the fp32 16x16x4 core on the widened values.  Returns the old value."""
+    return _lib.load().ldm_window_attention_bf16_core(v)
