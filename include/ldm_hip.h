@@ -310,6 +310,9 @@ int ldm_gemm_bf16(const ldm_gemm_desc *d, int out_bf16, void *stream);
  * in-projection of a zero row stores); dbias_pad [3C] stays fp32. */
 int ldm_window_attention_bwd_bf16(const void *qkv, const float *in_proj_bias, const void *xf, const void *dctx, void *dqkv, float *dbias_pad,
                                   int B, int H, int W, int C, int ws, int shift, void *stream);
+/* core of ldm_window_attention_bwd_bf16: 1 (default) = all seven products on the bf16 matrix cores (P and dS rounded once to bf16 as the
+ * operands of the token contractions; scores, softmax, dS in fp32), 0 = the fp32 16x16x4 core on the widened values.  Returns the old value. */
+int ldm_window_attention_bwd_bf16_core(int v);
 /* ReGLU forward in one launch (modules.py:14-15): d->act == LDM_ACT_GATE, d->w / d->w2 (+ bias / bias2) the "a" / "b" branches,
  * d->out = a * relu(b) as bf16 [M, ldo]; a_pre / b_pre (both or neither): bf16 [M, ldo] copies of the pre-activations a, b that
  * the backward needs.  ldm_gemm_bf16_gate_bwd is the data-gradient GEMM dh = dy . Wc (d as for ldm_gemm_bf16) with the gate's

@@ -146,6 +146,7 @@ SIGNATURES = {
     # bf16 training step
     "ldm_gemm_bf16": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
     "ldm_window_attention_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_window_attention_bwd_bf16_core": (_I, [_I]),
     "ldm_gemm_bf16_gate_fwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P]),
     "ldm_gemm_bf16_gate_bwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P, _P]),
     "ldm_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),

@@ -1152,6 +1152,314 @@ __global__ __launch_bounds__(128, 2) void window_attention_bwd_mfma_kernel(const
     }
 }
 
+// ---- bf16 matrix-core version (bf16 rows in and out: the bf16 training step) ------------------------------------------------------------
+// The same five products in both orientations, on the bf16 matrix cores: the four d-contractions (S^T = K Q^T, dP^T = V dO^T, S = Q K^T,
+// dP = dO V^T) are ONE v_mfma_f32_16x16x32_bf16 per tile -- a lane's operand is one 16-byte load of the token's bf16 row -- and the three
+// token-contractions (dQ^T = K^T dS^T, dK^T = Q^T dS, dV^T = dO^T P) are v_mfma_f32_16x16x16_bf16 whose B operand is the score tile's own
+// registers (P, dS rounded once to bf16) and whose A operand comes from LDS images of K, Q, dO ([token][32 dims] bf16, 80-byte rows, rows
+// past L zero) through the transposing read ds_read_b64_tr_b16.  The 1/sqrt(32) scale is applied to the fp32 scores and to dq, dk (the
+// images hold the unscaled q).  Scores, softmax, dS in fp32 as before.  90 matrix instructions of 8-16 cycles instead of 360 of 32.
+typedef short bwfrag8 __attribute__((ext_vector_type(8)));
+typedef short bwfrag4 __attribute__((ext_vector_type(4)));
+typedef unsigned bwu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bwu32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) bwfrag4 *lds_bwfrag4_ptr;
+
+__device__ __forceinline__ unsigned bw_pack2(float lo, float hi)
+{
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const f32x2v v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+__device__ __forceinline__ bwu32x4 bw_bias8(const float *b)
+{
+    const f32x4 b0 = *(const f32x4 *)b, b1 = *(const f32x4 *)(b + 4);
+    return bwu32x4{bw_pack2(b0[0], b0[1]), bw_pack2(b0[2], b0[3]), bw_pack2(b1[0], b1[1]), bw_pack2(b1[2], b1[3])};
+}
+__device__ __forceinline__ bwfrag4 bw_pack4(const f32x4 &v)
+{
+    const bwu32x2 w = {bw_pack2(v[0], v[1]), bw_pack2(v[2], v[3])};
+    return __builtin_bit_cast(bwfrag4, w);
+}
+
+template <int NT>
+__global__ __launch_bounds__(128, 2) void window_attention_bwd_bf16_kernel(const AttnB p)
+{
+    constexpr int LT = 16 * NT;
+    constexpr int VS = 80;                                    // bytes per image row (64 used)
+    constexpr int IMG = LT * VS;
+    constexpr int WB = 3 * IMG + LT * 4;                      // K, Q, dO images, then the key bias
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int L = p.L, C = p.C;
+    unsigned char *Ki = smem16 + wave * WB, *Qi = Ki + IMG, *Gi = Qi + IMG;
+    float *Kb = (float *)(Gi + IMG);
+    const long long gw = (long long)blockIdx.x * 2 + wave;
+    const bool active = gw < p.total_waves;
+    const int head = (int)(gw % p.heads);
+    const long long t1 = gw / p.heads;
+    const int nwin = p.global ? 1 : p.nwh * p.nww;
+    const int win = (int)(t1 % nwin);
+    const long long b = t1 / nwin;
+    const int wr = win / p.nww, wc = win - wr * p.nww;
+    const long long img = b * p.H * p.W;
+    const float scale = 0.17677669529663687f;
+
+    bwu32x4 kf[NT], qf[NT], vf[NT], gf[NT];
+    long long trow[NT];
+    bool tok[NT], tpad[NT];
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + c;
+            int sy = 0, sx = 0, py = 0, px = 0;
+            const bool ok = j < L && tok_src(p, wr, wc, j, sy, sx, py, px);
+            tok[t] = ok;
+            tpad[t] = j < L && !ok;
+            trow[t] = img + (long long)sy * p.W + sx;
+            const bwu32x4 z{0u, 0u, 0u, 0u};
+            if (ok) {
+                const unsigned short *row16 = p.qkv16 + trow[t] * 3 * C + head * 32 + 8 * g;
+                qf[t] = *(const bwu32x4 *)row16;
+                kf[t] = *(const bwu32x4 *)(row16 + C);
+                vf[t] = *(const bwu32x4 *)(row16 + 2 * C);
+                gf[t] = *(const bwu32x4 *)(p.dctx16 + trow[t] * C + head * 32 + 8 * g);
+            } else if (j < L) {                               // zero-padded token: q, k, v = the bias as the bf16 projection stored it; dO = 0
+                qf[t] = bw_bias8(p.bias + head * 32 + 8 * g);
+                kf[t] = bw_bias8(p.bias + C + head * 32 + 8 * g);
+                vf[t] = bw_bias8(p.bias + 2 * C + head * 32 + 8 * g);
+                gf[t] = z;
+            } else {                                          // rows past L: zeros everywhere (their key bias is -inf, their P row is forced to 0)
+                qf[t] = kf[t] = vf[t] = gf[t] = z;
+            }
+            *(bwu32x4 *)(Ki + j * VS + 16 * g) = kf[t];
+            *(bwu32x4 *)(Qi + j * VS + 16 * g) = qf[t];
+            *(bwu32x4 *)(Gi + j * VS + 16 * g) = gf[t];
+        }
+        if (lane < LT) {
+            float kb = -INFINITY;
+            if (lane < L) {
+                int sy, sx, py, px;
+                const bool ok = tok_src(p, wr, wc, lane, sy, sx, py, px);
+                kb = 0.f;
+                if (!p.global) {
+                    if (p.shift == 0) {
+                        kb = ok ? 0.f : -INFINITY;
+                    } else {
+                        int my = (py - 2 * p.shift) % p.Hp, mx = (px - 2 * p.shift) % p.Wp;
+                        my += my < 0 ? p.Hp : 0;
+                        mx += mx < 0 ? p.Wp : 0;
+                        kb = (my < p.H && mx < p.W) ? __uint_as_float((unsigned)p.xf16[(img + (long long)my * p.W + mx) * C] << 16) : 0.f;
+                    }
+                }
+            }
+            Kb[lane] = kb;
+        }
+    }
+    __syncthreads();
+    if (!active) return;                                      // whole waves only: the transposing reads need a full EXEC mask
+
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    const int tq = c >> 2, tp = c & 3;                         // this lane SUPPLIES row tq, columns 4 tp .. + 3 of its group's 4 x 16 block
+    auto tr_frag = [&](const unsigned char *image, int t, int dt) -> bwfrag4 {      // image rows 16 t + 4 g .. + 3, dims 16 dt .. + 15, transposed
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bwfrag4_ptr)(image + (16 * t + 4 * g + tq) * VS + (16 * dt + 4 * tp) * 2));
+    };
+    auto mm32 = [&](const bwu32x4 &a, const bwu32x4 &bq) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bwfrag8, a), __builtin_bit_cast(bwfrag8, bq), zero4, 0, 0, 0);
+    };
+    // ---- column orientation: S^T[k][q], dP^T[k][q]  ->  dS^T  ->  dQ ------------------------------------------------
+    {
+        f32x4 st[NT][NT], dpt[NT][NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                st[kt][qt] = mm32(kf[kt], qf[qt]);
+                dpt[kt][qt] = mm32(vf[kt], gf[qt]);
+            }
+        float kbv[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kbv[kt][e] = Kb[16 * kt + 4 * g + e];
+        bwfrag4 dsb[NT][NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][qt][e] = st[kt][qt][e] * scale + kbv[kt][e];
+                    mx = fmaxf(mx, st[kt][qt][e]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][qt][e] = __expf(st[kt][qt][e] - mx);
+                    sum += st[kt][qt][e];
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float dot = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][qt][e] *= inv;
+                    dot = fmaf(st[kt][qt][e], dpt[kt][qt][e], dot);
+                }
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[kt][qt][e] *= dpt[kt][qt][e] - dot;             // dS^T
+                dsb[kt][qt] = bw_pack4(st[kt][qt]);
+            }
+        }
+        f32x4 dq[NT][2];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) dq[qt][0] = dq[qt][1] = zero4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bwfrag4 a = tr_frag(Ki, kt, dt);                                         // K^T: dims x keys
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, dsb[kt][qt], dq[qt][dt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+            if (tok[qt]) {
+                const long long doff = trow[qt] * 3 * C + head * 32 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    store4_bf16(p.dqkv16 + doff + 16 * dt, f32x4{dq[qt][dt][0] * scale, dq[qt][dt][1] * scale, dq[qt][dt][2] * scale, dq[qt][dt][3] * scale});
+            }
+    }
+    // ---- row orientation: S[q][k], dP[q][k]  ->  P, dS  ->  dK, dV -----------------------------------------------------
+    f32x4 sm[NT][NT], dpm[NT][NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            sm[qt][kt] = mm32(qf[qt], kf[kt]);
+            dpm[qt][kt] = mm32(gf[qt], vf[kt]);
+        }
+    float kbc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) kbc[kt] = Kb[16 * kt + c];
+    auto row_max = [](float v) {
+        v = fmaxf(v, attn_dpp<0xB1>(v));
+        v = fmaxf(v, attn_dpp<0x4E>(v));
+        v = fmaxf(v, attn_dpp<0x141>(v));
+        return fmaxf(v, attn_dpp<0x140>(v));
+    };
+    auto row_sum = [](float v) {
+        v += attn_dpp<0xB1>(v);
+        v += attn_dpp<0x4E>(v);
+        v += attn_dpp<0x141>(v);
+        return v + attn_dpp<0x140>(v);
+    };
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                  // row q = 16 qt + 4 g + e, this lane's columns k = 16 kt + c
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt][e] = sm[qt][kt][e] * scale + kbc[kt];
+                mx = fmaxf(mx, sm[qt][kt][e]);
+            }
+            mx = row_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt][e] = __expf(sm[qt][kt][e] - mx);
+                sum += sm[qt][kt][e];
+            }
+            const float rsum = row_sum(sum);
+            const float inv = (16 * qt + 4 * g + e < L) ? 1.0f / rsum : 0.f;                // rows past L: P = 0
+            float dot = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                sm[qt][kt][e] *= inv;                                   // P
+                dot = fmaf(sm[qt][kt][e], dpm[qt][kt][e], dot);
+            }
+            dot = row_sum(dot);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) dpm[qt][kt][e] = sm[qt][kt][e] * (dpm[qt][kt][e] - dot);     // dS
+        }
+    f32x4 dk[NT][2], dv[NT][2];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) dk[kt][0] = dk[kt][1] = dv[kt][0] = dv[kt][1] = zero4;
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        bwfrag4 dsr[NT], pr[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            dsr[kt] = bw_pack4(dpm[qt][kt]);
+            pr[kt] = bw_pack4(sm[qt][kt]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const bwfrag4 aq = tr_frag(Qi, qt, dt), ag = tr_frag(Gi, qt, dt);                  // Q^T, dO^T: dims x queries
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, dsr[kt], dk[kt][dt], 0, 0, 0);
+                dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ag, pr[kt], dv[kt][dt], 0, 0, 0);
+            }
+        }
+    }
+    bool padded = false;
+    f32x4 pk[2], pv[2];
+    pk[0] = pk[1] = pv[0] = pv[1] = zero4;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dk[kt][dt][e] *= scale;
+        if (tok[kt]) {
+            const long long doff = trow[kt] * 3 * C + head * 32 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                store4_bf16(p.dqkv16 + doff + C + 16 * dt, dk[kt][dt]);
+                store4_bf16(p.dqkv16 + doff + 2 * C + 16 * dt, dv[kt][dt]);
+            }
+        } else if (tpad[kt]) {                    // k, v of a zero-padded token are the in-proj bias: their gradients belong to it
+            padded = true;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                pk[dt] += dk[kt][dt];
+                pv[dt] += dv[kt][dt];
+            }
+        }
+    }
+    if (__any(padded)) {                           // wave-uniform
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sk = row_sum(pk[dt][e]), sv = row_sum(pv[dt][e]);
+                if (c == 0) {
+                    p.pad_parts[gw * 64 + 16 * dt + 4 * g + e] = sk;
+                    p.pad_parts[gw * 64 + 32 + 16 * dt + 4 * g + e] = sv;
+                }
+            }
+    } else {
+        p.pad_parts[gw * 64 + lane] = 0.f;
+    }
+}
+
 // dbias_pad [3C] in two fixed-order steps.  Step 1 (grid heads x kPadRanges): block (h, r) adds the waves' (dk | dv) sums of head h over
 // its contiguous range r of (sample, window) pairs -- sixteen sub-ranges in pair order, then the sixteen sub-sums in order -- into
 // mid[(h * kPadRanges + r) * 64 + j].  Step 2 (one block per head): the ranges in order; the q third of the bias gets zeros.
@@ -1435,6 +1743,15 @@ extern "C" int ldm_window_attention_bwd_mfma(int v)
     return old;
 }
 
+int g_attn_bwd_bf16_core = 1;        // ldm_window_attention_bwd_bf16: 1 = bf16 matrix cores (default), 0 = the fp32 16x16x4 core (A/B tests)
+
+extern "C" int ldm_window_attention_bwd_bf16_core(int v)
+{
+    const int old = g_attn_bwd_bf16_core;
+    if (v == 0 || v == 1) g_attn_bwd_bf16_core = v;
+    return old;
+}
+
 static int attention_bwd_impl(const char *who, const void *qkv, const float *in_proj_bias, const void *xf, const void *dctx, void *dqkv, float *dbias_pad,
                               int B, int H, int W, int C, int ws, int shift, bool io16, void *stream)
 {
@@ -1463,7 +1780,13 @@ static int attention_bwd_impl(const char *who, const void *qkv, const float *in_
     if (!p.pad_parts) return LDM_ELAUNCH;
     float *pad_mid = p.pad_parts + (size_t)p.total_waves * 64;
     const dim3 grid((unsigned)((p.total_waves + 1) / 2));
-    if (g_attn_bwd_mfma || io16) {                      // every window the reference builds has L <= 36
+    if (io16 && g_attn_bwd_bf16_core && p.L <= 48 && (p.global || p.shift == 0 || xf)) {      // bf16 rows in and out: the bf16 matrix cores
+        const int nt = (p.L + 15) / 16;
+        const size_t smem = 2ull * (3 * 16 * nt * 80 + 16 * nt * 4);
+        if (nt == 1) hipLaunchKernelGGL(window_attention_bwd_bf16_kernel<1>, grid, dim3(128), smem, st, p);
+        else if (nt == 2) hipLaunchKernelGGL(window_attention_bwd_bf16_kernel<2>, grid, dim3(128), smem, st, p);
+        else hipLaunchKernelGGL(window_attention_bwd_bf16_kernel<3>, grid, dim3(128), smem, st, p);
+    } else if (g_attn_bwd_mfma || io16) {               // every window the reference builds has L <= 36
         const int nt = (p.L + 15) / 16;
         const size_t smem = 2ull * (3 * p.L * 36 + 16 * nt) * sizeof(float);
         if (nt == 1) hipLaunchKernelGGL(window_attention_bwd_mfma_kernel<1>, grid, dim3(128), smem, st, p);

@@ -635,3 +635,8 @@ def replicate(src, reps):
 def window_attention_bf16_core(v):
     """1 (default): bf16-QKV attention on the bf16 matrix cores; 0: the fp32 16x16x4 core on the widened values.  Returns the old value."""
     return _lib.load().ldm_window_attention_bf16_core(v)
+
+
+def window_attention_bwd_bf16_core(v):
+    """1 (default): window_attention_bwd_bf16 on the bf16 matrix cores; 0: the fp32 16x16x4 core on the widened values.  Returns the old value."""
+    return _lib.load().ldm_window_attention_bwd_bf16_core(v)

@@ -357,3 +357,36 @@ def test_gemm_bf16_gate_forward_ring_kernel_bit_identical_to_stream_kernel(gpu_d
     b_ref = torch.cat([xd @ w.double().t() + b_.double() for w, b_ in zip(wb, bb)], 1)
     assert rel_l2(outs[2][1].double().cpu(), a_ref.cpu()) < 3e-3 and rel_l2(outs[2][2].double().cpu(), b_ref.cpu()) < 3e-3
     assert rel_l2(outs[2][0].double().cpu(), (a_ref * torch.relu(b_ref)).cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+@pytest.mark.parametrize("hw", [(8, 8), (16, 16), (4, 4), (7, 9), (32, 32)])
+def test_window_attention_backward_bf16_rows(gpu_device, shift, hw):
+    """Attention backward with bf16 rows in and out: (a) the fp32 16x16x4 core behind the bf16 entry point equals the fp32 entry point
+    on the widened inputs, rounded once (exact); (b) the bf16 matrix-core kernel (P and dS rounded to bf16 as operands) stays within
+    bf16 rounding of it."""
+    from ldm_image_generator_amd import ops
+    B, C = 2, 64
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 100 + W + shift)
+    qkv = bf(torch.randn(B * H * W, 3 * C, generator=g)).cuda()
+    bias = bf(torch.randn(3 * C, generator=g)).float().cuda()
+    xf = bf(torch.randn(B * H * W, C, generator=g)).cuda()
+    dctx = bf(torch.randn(B * H * W, C, generator=g)).cuda()
+    ref = torch.empty(B * H * W, 3 * C, device=gpu_device)
+    pad_ref = torch.empty(3 * C, device=gpu_device)
+    ops.window_attention_bwd(qkv.float(), bias, xf.float(), dctx.float(), ref, pad_ref, B, H, W, C, 6, shift)
+    outs = {}
+    for core in (0, 1):
+        old = ops.window_attention_bwd_bf16_core(core)
+        dq = torch.empty(B * H * W, 3 * C, device=gpu_device, dtype=BF)
+        pad = torch.empty(3 * C, device=gpu_device)
+        ops.window_attention_bwd_bf16(qkv, bias, xf, dctx, dq, pad, B, H, W, C, 6, shift)
+        ops.window_attention_bwd_bf16_core(old)
+        outs[core] = (dq, pad)
+    assert torch.equal(outs[0][0], bf(ref)) and torch.equal(outs[0][1], pad_ref)
+    assert rel_l2(outs[1][0].float().cpu(), ref.cpu()) < 8e-3
+    if float(pad_ref.abs().max()) > 0:
+        assert rel_l2(outs[1][1].cpu(), pad_ref.cpu()) < 8e-3
+    else:
+        assert float(outs[1][1].abs().max()) == 0.0
