@@ -382,6 +382,9 @@ int ldm_rgb_head_bwd_f32(const float *drgb, const float *w, const float *rows, f
  * layout: output channel, tap, input channel), bias [C] / addend [B*H*W, C] fp32 or NULL, out fp32 (may alias addend).
  * The data gradient is the same call on dy with the flipped, in/out-swapped filter. */
 int ldm_gconv3x3_bf16(const void *x, const void *w, const float *bias, const float *addend, float *out, int B, int H, int W, int C, void *stream);
+/* kernel behind ldm_gconv3x3_bf16: 1 (default) = the LDS-tiled kernel where the shape allows (W a power of two in 8 .. 64, H a multiple of the
+ * tile's rows, an even number of groups), 0 = the direct-from-global kernel everywhere.  Bit-identical results; A/B knob.  Returns the old value. */
+int ldm_gconv3x3_bf16_tiled(int v);
 
 /* Weight gradient of the same layer from bf16 x and dy [B*H*W, C]: out_planes[(s * 4 + w)][C][288] fp32 (288 = tap * 32 + ci),
  * s < splits, w < 4; the caller sums the 4 * splits planes (ldm_reduce_partials_f32).  ldm_gconv3x3_wgrad_bf16_splits suggests splits. */

@@ -1547,8 +1547,10 @@ extern "C" int ldm_colsum_f32(const float *x, float *out, long long M, int N, in
 {
     LDM_REQUIRE(x && out && M > 0 && N > 0, "ldm_colsum_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    // ~256 slabs whatever M is: enough blocks to fill the chip, few enough planes for the fixed-order sum
-    long long slab = (M + 255) / 256;
+    // slabs of >= 64 rows, ~2048 of them for a long matrix: with N <= 256 columns a slab is ONE workgroup, so the slab count is the kernel's
+    // whole parallelism (256 slabs of 2048 rows ran the stem's bias gradient -- 524 288 x 128 -- at 0.27 TB/s); the fixed-order sum of a
+    // few thousand N-float planes is cheap
+    long long slab = (M + 2047) / 2048;
     slab = slab < 64 ? 64 : slab;
     const unsigned slabs = blocks_for(M, (int)slab);
     if (slabs == 1 && !accumulate) {

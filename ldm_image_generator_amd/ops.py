@@ -640,3 +640,8 @@ def window_attention_bf16_core(v):
 def window_attention_bwd_bf16_core(v):
     """1 (default): window_attention_bwd_bf16 on the bf16 matrix cores; 0: the fp32 16x16x4 core on the widened values.  Returns the old value."""
     return _lib.load().ldm_window_attention_bwd_bf16_core(v)
+
+
+def gconv3x3_bf16_tiled(v):
+    """1 (default): LDS-tiled bf16 grouped conv where the shape allows; 0: the direct kernel.  Bit-identical.  Returns the old value."""
+    return _lib.load().ldm_gconv3x3_bf16_tiled(v)

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 5, 7, 32), (3, 16, 16, 128), (2, 4, 4, 1024), (1, 64, 64, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 5, 7, 32), (3, 16, 16, 128), (2, 4, 4, 1024), (1, 64, 64, 128), (2, 32, 32, 256), (1, 4, 8, 64)])
 def test_gconv3x3_bf16_forward_and_data_gradient(gpu_device, B, H, W, C):
     from ldm_image_generator_amd import ops
     g = torch.Generator().manual_seed(B * H + C)
@@ -25,6 +25,12 @@ def test_gconv3x3_bf16_forward_and_data_gradient(gpu_device, B, H, W, C):
     ops.gconv3x3_bf16(rows, packed, bias.cuda(), res_rows, out, B, H, W, C)
     got = out.cpu().reshape(B, H, W, C).permute(0, 3, 1, 2)
     assert rel_l2(got, ref) < 1e-5
+    # the LDS-tiled kernel (taken above where the shape allows) and the direct kernel run the same MFMA order: bit-identical
+    old = ops.gconv3x3_bf16_tiled(0)
+    out_direct = torch.full((B * H * W, C), float("nan"), device=gpu_device)
+    ops.gconv3x3_bf16(rows, packed, bias.cuda(), res_rows, out_direct, B, H, W, C)
+    ops.gconv3x3_bf16_tiled(old)
+    assert torch.equal(out, out_direct)
     # data gradient: conv of dy with the spatially flipped, in/out-swapped filter, accumulated in place
     dy = torch.randn(B, C, H, W, generator=g).to(BF)
     xin = x.double().requires_grad_()
