@@ -450,6 +450,10 @@ typedef struct ldm_unet_plan_bf16 {
     const ldm_unet_block_bf16 *blocks;       /* HOST array, execution order */
 } ldm_unet_plan_bf16;
 /* ldm_unet_forward_ex_f32 in the bf16 mode (same workspace size, same arguments); every stage width must be a multiple of 64 */
+/* streams of the native executor: 1 (default) = everything on the caller's stream; 2 = the gated GEMM of every SwinBlock on a library-owned
+ * side stream beside the grouped conv / attention branch (event fork / join on the caller's stream; bit-identical results).  LDM_UNET_STREAMS
+ * in the environment sets the initial value.  Returns the previous setting; any other v only queries. */
+int ldm_unet_streams(int v);
 int ldm_unet_forward_bf16(const ldm_unet_plan *plan, const ldm_unet_plan_bf16 *plan16, const float *x, const long long *t_unique, int nT,
                           const int *slot, const int *decisions, int B, int H, int W, void *workspace, size_t workspace_bytes, float *out,
                           int films_ready, void *stream);

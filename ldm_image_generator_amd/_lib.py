@@ -186,6 +186,7 @@ SIGNATURES = {
     "ldm_rgb_head_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_up2_add_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_avgpool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ldm_unet_streams": (_I, [_I]),
     "ldm_unet_forward_bf16": (_I, [ctypes.POINTER(UNetPlanDesc), ctypes.POINTER(UNetPlan16Desc), _P, _P, _I, _P, ctypes.POINTER(ctypes.c_int), _I, _I, _I,
                                    _P, ctypes.c_size_t, _P, _I, _P]),
 }

@@ -106,6 +106,37 @@ long long unet_chunk_bytes(bool bf16)
     return mb << 20;
 }
 
+// Second stream of the executor.  Inside a SwinBlock the gated GEMM of the MoE reads only the normalised input, like the grouped conv
+// (and the attention chain): the two branches meet again at the K-segment GEMM.  With LDM_UNET_STREAMS=2 (or ldm_unet_streams(2)) the gated
+// GEMM runs on a side stream between an event fork and join, so the tail of one branch's last tile round overlaps the head of the
+// other's.  Same kernels on the same operands: results are bit-identical.  Off by default until measured.
+int g_unet_streams = -1;             // -1: read LDM_UNET_STREAMS once; 1: one stream; 2: fork the gated GEMM
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false, tried = false;
+};
+SideStream g_side[64];
+SideStream *side_stream()
+{
+    if (g_unet_streams < 0) {
+        const char *e = getenv("LDM_UNET_STREAMS");
+        g_unet_streams = e ? atoi(e) : 1;
+    }
+    if (g_unet_streams < 2) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SideStream &s = g_side[dev & 63];
+    if (!s.tried) {
+        s.tried = true;
+        s.ok = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+        if (!s.ok) (void)hipGetLastError();
+    }
+    return s.ok ? &s : nullptr;
+}
+
 #define RUN(call)                    \
     do {                             \
         const int rc_ = (call);      \
@@ -152,6 +183,25 @@ int run_block_bf16(const ldm_unet_plan *pl, const ldm_unet_block *bk, const ldm_
     const long long M = lv.M;
     void *xf16 = L.xf, *hid16 = L.hidden, *ctx16 = L.ctx;
     RUN(ldm_channelnorm_film_bf16(x, film, slot, nullptr, xf16, B, lv.H * lv.W, C, pl->eps, st));
+    const int e1 = decision >> 2, e2 = decision & 3;
+    const int sel[3] = {0, 1 + e1, 1 + e2};
+    auto gated = [&](void *stream) -> int {
+        ldm_gemm_desc g = gemm_rows16(xf16, M, 3 * C, C, nullptr, nullptr, hid16);
+        g.nseg = 3; g.seg_mode = LDM_SEG_N; g.seg_len = C; g.act = LDM_ACT_GATE;
+        for (int s = 0; s < 3; ++s) {
+            g.w[s] = (const float *)b16->a_w[sel[s]]; g.bias[s] = bk->a_b[sel[s]];
+            g.w2[s] = (const float *)b16->b_w[sel[s]]; g.bias2[s] = bk->b_b[sel[s]];
+        }
+        return ldm_gemm_bf16_gate_fwd(&g, nullptr, nullptr, stream);
+    };
+    SideStream *ss = side_stream();
+    if (ss) {
+        if (hipEventRecord(ss->fork, (hipStream_t)st) != hipSuccess || hipStreamWaitEvent(ss->side, ss->fork, 0) != hipSuccess) ss = nullptr;
+    }
+    if (ss) {
+        RUN(gated(ss->side));
+        if (hipEventRecord(ss->join, ss->side) != hipSuccess) { ldm_set_error("ldm_unet_forward: event record failed"); return LDM_ELAUNCH; }
+    }
     RUN(ldm_gconv3x3_bf16(xf16, b16->conv_w, bk->conv_b, x, y, B, lv.H, lv.W, C, st));           // y = conv3x3_grouped(xf) + bias + x
     if (bk->attention) {
         ldm_gemm_desc q = gemm_rows16(xf16, M, 3 * C, C, b16->in_w, bk->in_b, L.qkv);           // q, k, v as bf16 rows (half the bytes each way)
@@ -161,16 +211,12 @@ int run_block_bf16(const ldm_unet_plan *pl, const ldm_unet_block *bk, const ldm_
         o.addend = y; o.ldadd = C;
         RUN(ldm_gemm_bf16(&o, 0, st));
     }
-    const int e1 = decision >> 2, e2 = decision & 3;
-    const int sel[3] = {0, 1 + e1, 1 + e2};
     {
-        ldm_gemm_desc g = gemm_rows16(xf16, M, 3 * C, C, nullptr, nullptr, hid16);
-        g.nseg = 3; g.seg_mode = LDM_SEG_N; g.seg_len = C; g.act = LDM_ACT_GATE;
-        for (int s = 0; s < 3; ++s) {
-            g.w[s] = (const float *)b16->a_w[sel[s]]; g.bias[s] = bk->a_b[sel[s]];
-            g.w2[s] = (const float *)b16->b_w[sel[s]]; g.bias2[s] = bk->b_b[sel[s]];
+        if (ss) {
+            if (hipStreamWaitEvent((hipStream_t)st, ss->join, 0) != hipSuccess) { ldm_set_error("ldm_unet_forward: stream wait failed"); return LDM_ELAUNCH; }
+        } else {
+            RUN(gated(st));
         }
-        RUN(ldm_gemm_bf16_gate_fwd(&g, nullptr, nullptr, st));
         ldm_gemm_desc c = gemm_rows16(hid16, M, C, 3 * C, nullptr, nullptr, y);
         c.nseg = 3; c.seg_mode = LDM_SEG_K; c.seg_len = C; c.ldw = C;
         for (int s = 0; s < 3; ++s) { c.w[s] = (const float *)b16->c_w[sel[s]]; c.bias[s] = bk->c_b[sel[s]]; }
@@ -187,6 +233,26 @@ int run_block(const ldm_unet_plan *pl, const ldm_unet_block *bk, int decision, c
     const int C = lv.C;
     const long long M = lv.M;
     RUN(ldm_channelnorm_film_f32(x, film, slot, L.xf, B, lv.H * lv.W, C, pl->eps, st));
+    const int e1 = decision >> 2, e2 = decision & 3;
+    const int sel[3] = {0, 1 + e1, 1 + e2};                  // general + the two drawn experts (modules.py:35-36)
+    auto gated = [&](void *stream) -> int {
+        ldm_gemm_desc g = gemm_rows(L.xf, M, 3 * C, C, nullptr, nullptr, L.hidden);
+        g.nseg = 3; g.seg_mode = LDM_SEG_N; g.seg_len = C; g.act = LDM_ACT_GATE;
+        for (int s = 0; s < 3; ++s) {
+            g.w[s] = bk->a_w[sel[s]]; g.bias[s] = bk->a_b[sel[s]];
+            g.w2[s] = bk->b_w[sel[s]]; g.bias2[s] = bk->b_b[sel[s]];
+        }
+        allow_splitk(g, L);
+        return ldm_gemm_f32(&g, stream);
+    };
+    SideStream *ss = M > 128 ? side_stream() : nullptr;      // small batches share one split-K scratch: one stream
+    if (ss) {
+        if (hipEventRecord(ss->fork, (hipStream_t)st) != hipSuccess || hipStreamWaitEvent(ss->side, ss->fork, 0) != hipSuccess) ss = nullptr;
+    }
+    if (ss) {
+        RUN(gated(ss->side));
+        if (hipEventRecord(ss->join, ss->side) != hipSuccess) { ldm_set_error("ldm_unet_forward: event record failed"); return LDM_ELAUNCH; }
+    }
     {   // y = conv3x3_grouped(xf) + bias + x
         ldm_gemm_desc d = gemm_rows(L.xf, M, 32, 288, bk->conv_w, bk->conv_b, y);
         d.lda = C; d.ldw = 288; d.a_mode = LDM_A_CONV3X3; d.H = lv.H; d.W = lv.W; d.Cin = 32;
@@ -204,17 +270,12 @@ int run_block(const ldm_unet_plan *pl, const ldm_unet_block *bk, int decision, c
         allow_splitk(o, L);
         RUN(ldm_gemm_f32(&o, st));
     }
-    const int e1 = decision >> 2, e2 = decision & 3;
-    const int sel[3] = {0, 1 + e1, 1 + e2};                  // general + the two drawn experts (modules.py:35-36)
     {
-        ldm_gemm_desc g = gemm_rows(L.xf, M, 3 * C, C, nullptr, nullptr, L.hidden);
-        g.nseg = 3; g.seg_mode = LDM_SEG_N; g.seg_len = C; g.act = LDM_ACT_GATE;
-        for (int s = 0; s < 3; ++s) {
-            g.w[s] = bk->a_w[sel[s]]; g.bias[s] = bk->a_b[sel[s]];
-            g.w2[s] = bk->b_w[sel[s]]; g.bias2[s] = bk->b_b[sel[s]];
+        if (ss) {
+            if (hipStreamWaitEvent((hipStream_t)st, ss->join, 0) != hipSuccess) { ldm_set_error("ldm_unet_forward: stream wait failed"); return LDM_ELAUNCH; }
+        } else {
+            RUN(gated(st));
         }
-        allow_splitk(g, L);
-        RUN(ldm_gemm_f32(&g, st));
         ldm_gemm_desc c = gemm_rows(L.hidden, M, C, 3 * C, nullptr, nullptr, y);
         c.nseg = 3; c.seg_mode = LDM_SEG_K; c.seg_len = C; c.ldw = C;
         for (int s = 0; s < 3; ++s) { c.w[s] = bk->c_w[sel[s]]; c.bias[s] = bk->c_b[sel[s]]; }
@@ -375,4 +436,14 @@ static int unet_forward_impl(const ldm_unet_plan *pl, const ldm_unet_plan_bf16 *
     }
     RUN(ldm_head_nchw_f32(L.act[0][cur[0]], pl->head_w, pl->head_b, out, B, lv[0].C, H * W, pl->input_channels, st));
     return LDM_OK;
+}
+
+// 1: the executor uses one stream; 2: the gated GEMM of every SwinBlock runs on a side stream beside the grouped conv / attention
+// branch (bit-identical results).  Returns the previous setting; any other v only queries.
+extern "C" int ldm_unet_streams(int v)
+{
+    if (g_unet_streams < 0) (void)side_stream();
+    const int old = g_unet_streams;
+    if (v == 1 || v == 2) g_unet_streams = v;
+    return old;
 }
