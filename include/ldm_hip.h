@@ -323,6 +323,9 @@ int ldm_gemm_bf16_gate_bwd(const ldm_gemm_desc *d, const void *a_pre, const void
  * out[s][n][k] fp32 = sum over the rows m of split s of a[m*lda + n] * b[m*ldb + k]; colsum_a optional [splits][N] fp32. */
 int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, long long ldb, float *out, float *colsum_a, int M, int N, int K, int splits,
                      void *stream);
+/* kernel behind ldm_gemm_tn_bf16: 1 (default) = 256 x 256 tiles with one workgroup of eight waves per CU and a four-stage LDS ring where N and K are
+ * multiples of 256 and tiles x splits fill the chip, 0 = the 128-row kernel everywhere.  Bit-identical results.  Returns the previous setting. */
+int ldm_gemm_tn_ring(int v);
 int ldm_cast_bf16(const float *x, void *out, long long n, void *stream);                       /* out = bf16(x), n % 4 == 0          */
 int ldm_uncast_bf16(const void *x, float *out, long long n, void *stream);                      /* out = fp32(x), exact               */
 int ldm_transpose_cast_bf16(const float *x, void *out, long long R, int C, void *stream);      /* out[C][R] = bf16(x[R][C]^T)        */

@@ -150,6 +150,7 @@ SIGNATURES = {
     "ldm_gemm_bf16_gate_fwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P]),
     "ldm_gemm_bf16_gate_bwd": (_I, [ctypes.POINTER(GemmDesc), _P, _P, _P, _P]),
     "ldm_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_gemm_tn_ring": (_I, [_I]),
     "ldm_cast_bf16": (_I, [_P, _P, _L, _P]),
     "ldm_uncast_bf16": (_I, [_P, _P, _L, _P]),
     "ldm_transpose_cast_bf16": (_I, [_P, _P, _L, _I, _P]),

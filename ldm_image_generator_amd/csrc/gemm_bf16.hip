@@ -288,6 +288,131 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
         }
 }
 
+
+// ---- 256 x 256 tiles, ONE workgroup of eight waves per CU ("TN ring") -------------------------------------------------------------------
+// The 128 x 256 kernel above moves 24.6 KB of operands per stage for 2.1 MFLOP (85 FLOP per staged byte): at its 640-680 TFLOP/s it
+// pulls 7.5 TB/s through L2 -- every A panel is re-read by K / 256 tiles and every B panel by N / 128.  A 256 x 256 tile halves the staged
+// bytes per FLOP (170 FLOP / B): eight waves as 2 (n) x 4 (k), each 128 x 64 (the same eight accumulator tiles as above), a stage =
+// 32 contraction rows of two A sub-tiles and two B sub-tiles (32 KB), FOUR stages (three in flight behind counted vmcnt waits, one raw
+// barrier per stage), four LDS-DMA instructions per wave and stage.  Same sub-tile images, swizzle and transposing reads; the k order
+// of every output element is that of the kernel above -> bit-identical results.
+__global__ __launch_bounds__(512, 1) void gemm_tn_bf16_ring_kernel(const TnP16 p)
+{
+    constexpr int NS = 4, LOOK = NS - 1, PW = 4;
+    constexpr int STAGE = 4 * TSUB;                      // bf16 elements: A sub-tiles 0, 1, then B sub-tiles 0, 1
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int T = p.ntn * p.ntk;
+    int tile, split;
+    if (p.splits % 8 == 0) {               // tiles of one split on one XCD (they read the same operand rows)
+        const int b = (int)blockIdx.x, blk = b / (8 * T), in = b - blk * 8 * T;
+        split = blk * 8 + (in & 7);
+        tile = in >> 3;
+    } else {
+        tile = (int)blockIdx.x % T;
+        split = (int)blockIdx.x / T;
+    }
+    const int n0 = (tile / p.ntk) * 256, k0 = (tile % p.ntk) * 256;
+    const long long row0 = (long long)split * p.ms;
+    const int nsteps = p.ms / TBR;
+
+    // DMA: one instruction = 4 rows of one sub-tile; a sub-tile's 32 rows are 8 instructions, the stage's 4 sub-tiles 32: wave w moves
+    // instruction pieces 4 w .. 4 w + 3 (sub-tile = piece >> 3, rows 4 (piece & 7) .. + 3)
+    const int drow = lane >> 4, dchunk = lane & 15;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short *)lds16;
+    auto issue = [&](int step) {
+        const long long mbase = row0 + (long long)step * TBR;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int piece = 4 * wave + i;
+            const int sub = piece >> 3, row = 4 * (piece & 7) + drow;
+            const int csrc = (dchunk ^ tn_swz(row)) * 8;
+            const unsigned short *src = sub < 2 ? p.a + (mbase + row) * p.lda + n0 + sub * TBT + csrc : p.b + (mbase + row) * p.ldb + k0 + (sub - 2) * TBT + csrc;
+            glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((step % NS) * STAGE + sub * TSUB + 4 * (piece & 7) * TBT) * 2)));
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto frag = [&](const unsigned short *base, int mb, int c0) -> s16x8 {
+        const int col = c0 + 16 * (grp & 1) + 4 * pp;
+        const int rowa = mb + 8 * (grp >> 1) + q, rowb = rowa + 4;
+        const unsigned short *pa = base + rowa * TBT + (((col >> 3) ^ tn_swz(rowa)) << 3) + (col & 7);
+        const unsigned short *pb = base + rowb * TBT + (((col >> 3) ^ tn_swz(rowb)) << 3) + (col & 7);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pa);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pb);
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    const bool want_cs = p.colsum != nullptr && k0 == 0 && wn == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < LOOK; ++s0)
+        if (s0 < nsteps) issue(s0);
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        const int younger = nsteps - 1 - step < LOOK - 1 ? nsteps - 1 - step : LOOK - 1;
+        if (younger >= 2) tn_wait_vmcnt<2 * PW>();
+        else if (younger == 1) tn_wait_vmcnt<PW>();
+        else tn_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + LOOK < nsteps) issue(step + LOOK);
+        const unsigned short *St = lds16 + (step % NS) * STAGE;
+#pragma unroll
+        for (int s = 0; s < TBR / 16; ++s) {
+            s16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag(St + wm * TSUB, 16 * s, 32 * i);                // A sub-tile wm: this wave's 128 n-columns
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = wn * 64 + 32 * j;                                                  // column inside the tile's 256 k-columns
+                b[j] = frag(St + (2 + c / TBT) * TSUB, 16 * s, c % TBT);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (want_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[i] += bf16_lo((unsigned)(unsigned short)a[i][e]);
+            }
+        }
+    }
+
+    const int r = lane & 31, h = lane >> 5;
+    if (want_cs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s_ = cs[i] + __shfl_xor(cs[i], 32);
+            if (h == 0) p.colsum[(long long)split * p.N + n0 + wm * 128 + 32 * i + r] = s_;
+        }
+    }
+    float *obase = p.out + (long long)split * p.N * p.K + (long long)(n0 + wm * 128) * p.K + k0 + wn * 64 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) obase[(long long)row * p.K + 32 * j] = acc[i][j][e];
+        }
+}
+
+int g_tn_ring = 1;        // 1 (default): 256 x 256 tiles where N, K allow and the grid fills the CUs; 0: the 128-row kernel everywhere (bit-identical)
+
 template <int KT>
 void tn_launch(const TnP16 &p, long long blocks, hipStream_t st)
 {
@@ -311,15 +436,36 @@ extern "C" int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, lon
     TnP16 p{};
     p.a = (const unsigned short *)a; p.b = (const unsigned short *)b; p.out = out; p.colsum = colsum_a; p.lda = lda; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.ms = M / splits; p.splits = splits; p.ntn = N / TBT;
+    void *rec = ldm_prof_begin(LDM_PROF_TN_BF16, 2.0 * M * (double)N * K, (hipStream_t)stream, 2.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
+    // 256 x 256 tiles, one workgroup per CU, where N and K allow and the tiles x splits still give every CU a workgroup
+    const long long ring_blocks = (long long)(N / 256) * (K / 256) * splits;
+    static LdmLdsOptIn ring_opt;
+    constexpr size_t ring_smem = 4ull * 4 * TSUB * sizeof(unsigned short);                      // 128 KiB
+    if (g_tn_ring && N % 256 == 0 && K % 256 == 0 && ring_blocks >= (long long)ldm_cu_count() * 3 / 4 && ring_blocks <= 0x7fffffffLL &&
+        ring_opt((const void *)gemm_tn_bf16_ring_kernel, ring_smem)) {
+        p.ntn = N / 256; p.ntk = K / 256;
+        hipLaunchKernelGGL(gemm_tn_bf16_ring_kernel, dim3((unsigned)ring_blocks), dim3(512), ring_smem, (hipStream_t)stream, p);
+        ldm_prof_end(rec, (hipStream_t)stream);
+        LDM_CHECK_LAUNCH("ldm_gemm_tn_bf16");
+        return LDM_OK;
+    }
     // 128 x 256 tiles where K allows and the grid stays full: a third less operand traffic per output, twice the MFMAs per barrier
     const bool wide = K % (2 * TBT) == 0 && (long long)(N / TBT) * (K / (2 * TBT)) * splits >= 256;     // at least one workgroup per CU
     p.ntk = wide ? K / (2 * TBT) : K / TBT;
     const long long blocks = (long long)p.ntn * p.ntk * splits;
-    LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_gemm_tn_bf16: grid too large");
-    void *rec = ldm_prof_begin(LDM_PROF_TN_BF16, 2.0 * M * (double)N * K, (hipStream_t)stream, 2.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
+    if (blocks > 0x7fffffffLL) { ldm_prof_end(rec, (hipStream_t)stream); ldm_set_error("ldm_gemm_tn_bf16: grid too large"); return LDM_EINVAL; }
     if (wide) tn_launch<2>(p, blocks, (hipStream_t)stream);
     else tn_launch<1>(p, blocks, (hipStream_t)stream);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_gemm_tn_bf16");
     return LDM_OK;
+}
+
+// kernel behind ldm_gemm_tn_bf16: 1 (default) = 256 x 256 tiles, one workgroup per CU, where N and K are multiples of 256 and tiles x splits fill
+// the chip; 0 = the 128-row kernel everywhere.  Bit-identical results (A/B and test knob).  Returns the previous setting.
+extern "C" int ldm_gemm_tn_ring(int v)
+{
+    const int old = g_tn_ring;
+    if (v == 0 || v == 1) g_tn_ring = v;
+    return old;
 }

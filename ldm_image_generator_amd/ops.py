@@ -645,3 +645,8 @@ def window_attention_bwd_bf16_core(v):
 def gconv3x3_bf16_tiled(v):
     """1 (default): LDS-tiled bf16 grouped conv where the shape allows; 0: the direct kernel.  Bit-identical.  Returns the old value."""
     return _lib.load().ldm_gconv3x3_bf16_tiled(v)
+
+
+def gemm_tn_ring(v):
+    """1 (default): gemm_tn_bf16 on 256 x 256 tiles (one workgroup per CU) where the shape allows; 0: the 128-row kernel.  Returns the old value."""
+    return _lib.load().ldm_gemm_tn_ring(v)

@@ -514,6 +514,13 @@ _TN16_TARGET = int(_os.environ.get("LDM_TN16_TARGET", "256"))
 
 def tn16_splits(n_out, k_out, m_red):
     """Splits of the pixel reduction for ldm_gemm_tn_bf16: fill ~512 workgroups of 128 x 256 (K %% 256 == 0) or 128 x 128 tiles."""
+    if n_out % 256 == 0 and k_out % 256 == 0:                    # 256 x 256 tiles, one workgroup per CU (gemm_tn_bf16_ring_kernel):
+        tiles = (n_out // 256) * (k_out // 256)                    # ONE round of at most 256 workgroups (1.5 rounds ran slower than the 128-row kernel)
+        s = 1
+        while tiles * s * 2 <= _TN16_TARGET and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:
+            s *= 2
+        if tiles * s * 4 >= _TN16_TARGET * 3:                    # >= 3/4 of the CUs busy: the library takes the ring kernel
+            return s
     tiles = (n_out // 128) * (k_out // 256 if k_out % 256 == 0 else k_out // 128)
     s = 1
     while tiles * s < _TN16_TARGET and m_red % (2 * s) == 0 and (m_red // (2 * s)) % 64 == 0 and m_red // (2 * s) >= 256 and s < 256:

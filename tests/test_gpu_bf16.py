@@ -129,6 +129,28 @@ def test_gemm_tn_bf16(gpu_device, M, N, K, S):
     assert rel_l2(out.double().cpu(), (wide[:, :N].double().t() @ xw[:, :K].double()).cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,S", [(8192, 512, 512, 64), (16384, 256, 1024, 64), (4096, 768, 256, 64), (32768, 512, 256, 128)])
+def test_gemm_tn_bf16_ring_kernel_bit_identical(gpu_device, M, N, K, S):
+    """256 x 256 tiles with one workgroup per CU (N, K multiples of 256, tiles x splits >= 192) against the 128-row kernel: same k order of
+    every output element -> bit-identical partial planes and column sums; and both against fp64 on the same bf16 values."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = bf(torch.randn(M, N, generator=g)).cuda()
+    x = bf(torch.randn(M, K, generator=g)).cuda()
+    res = []
+    for ring in (0, 1):
+        old = ops.gemm_tn_ring(ring)
+        parts = torch.full((S, N, K), float("nan"), device=gpu_device)
+        cs = torch.full((S, N), float("nan"), device=gpu_device)
+        ops.gemm_tn_bf16(dy, x, parts, M, N, K, S, colsum=cs)
+        ops.gemm_tn_ring(old)
+        res.append((parts, cs))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    out = torch.empty(N, K, device=gpu_device)
+    ops.reduce_partials(res[1][0], S, N * K, out)
+    assert rel_l2(out.double().cpu(), (dy.double().t() @ x.double()).cpu()) < 1e-5
+
+
 def test_gemm_tn_bf16_exact_integer_layout(gpu_device):
     """Asymmetric small-integer operands: every product and sum is exact, so a wrong lane / row / column map of the
     transposing LDS reads shows as an integer mismatch, not as rounding noise."""
