@@ -264,6 +264,12 @@ int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n
  * [splits][N]) receives the column sums of `a` per split: the bias gradient that goes with dW. */
 int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, long long ldb, float *out, float *colsum_a, int M, int N, int K,
                     int splits, void *stream);
+/* Weight gradient of a dense 3x3 conv (zero pad 1; autograd of vae.py:57-58) without the im2col matrix -- the same kernel with an implicit
+ * B operand: out[s][n][tap * Cin + ci] = sum over the pixels m of split s of dy[m * lda + n] * x[(pixel m shifted by tap) * Cin + ci].
+ * out is [splits][Npad][Kpad], Npad = Cout and Kpad = 9 * Cin rounded up to multiples of 128 (the padding comes out as zeros); the caller
+ * sums the planes and takes the [Cout][9 * Cin] corner.  colsum_dy: optional [splits][Npad].  B*H*W / splits a multiple of 32. */
+int ldm_conv3x3_wgrad_f32(const float *dy, long long lda, const float *x, float *out, float *colsum_dy, int B, int H, int W, int Cin, int Cout,
+                          int splits, void *stream);
 /* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) per (slot, pixel): accumulated
  * atomically into a zeroed buffer when samples may share a slot, or -- unique_slots != 0: every sample has its own
  * slot -- written once with plain stores (no zeroing needed) */

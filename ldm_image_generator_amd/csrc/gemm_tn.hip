@@ -27,7 +27,13 @@ struct TnP {
     long long lda, ldb;
     int M, N, K, ms, splits;  // ms = rows per split
     int ntn, ntk;
+    // CONV (implicit weight gradient of a dense 3x3 conv, zero pad 1): b is the conv INPUT as rows [M = B*H*W, Cin]; column k of the
+    // virtual B matrix is (tap, ci) = (k / Cin, k % Cin) and its row m is x[pixel m shifted by the tap][ci] (0 outside the image, and
+    // for the padding taps >= 9 that make K a multiple of 128); Nreal <= N: columns of A past Nreal read zeros
+    int H, W, Cin, Nreal;
 };
+
+static __device__ __attribute__((aligned(64))) float tn_zero_block[16];
 
 constexpr int BT = 128;       // output tile edge
 constexpr int BR = 32;        // operand rows (contraction) per stage
@@ -35,6 +41,7 @@ constexpr int STAGE = 2 * BR * BT;
 
 // LDS rows are 512 B (32 chunks of 16 B).  The two half-waves of a fragment read touch rows m and m + 1: chunk bit 4
 // is XORed with (m & 1) so that they fall into different halves of the banks (applied on the DMA source side).
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -60,6 +67,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnP p)
 
     // DMA: one instruction = 64 lanes x 16 B = two rows of one operand tile; a wave moves rows {2 (4 i + wave), +1}
     const int lrow = lane >> 5, lchunk = lane & 31;
+    // CONV: this lane's two possible source chunks (row parity 0 / 1 swaps the halves of the 128-column tile) -> tap shift and channel
+    int c_shift[2] = {0, 0}, c_dy[2] = {0, 0}, c_dx[2] = {0, 0}, c_ci[2] = {0, 0};
+    bool c_tap_ok[2] = {true, true}, a_ok[2] = {true, true};
+    if constexpr (CONV) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int csrc = (lchunk ^ (par << 4)) * 4;
+            const int kcol = k0 + csrc;
+            const int tap = kcol / p.Cin;
+            c_ci[par] = kcol - tap * p.Cin;
+            c_tap_ok[par] = tap < 9;
+            c_dy[par] = tap / 3 - 1;
+            c_dx[par] = tap - (tap / 3) * 3 - 1;
+            c_shift[par] = c_dy[par] * p.W + c_dx[par];
+            a_ok[par] = n0 + csrc < p.Nreal;
+        }
+    }
     auto issue = [&](int step) {
         float *As = lds + (step & 1) * STAGE, *Bs = As + BR * BT;
         const long long mbase = row0 + (long long)step * BR;
@@ -67,8 +91,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnP p)
         for (int i = 0; i < 4; ++i) {
             const int row = 2 * (4 * i + wave) + lrow;
             const int csrc = (lchunk ^ ((row & 1) << 4)) * 4;
-            glds16(p.a + (mbase + row) * p.lda + n0 + csrc, As + (4 * i + wave) * 256);
-            glds16(p.b + (mbase + row) * p.ldb + k0 + csrc, Bs + (4 * i + wave) * 256);
+            if constexpr (CONV) {
+                const int par = row & 1;
+                const long long m = mbase + row;
+                const int xx = (int)(m % p.W), yy = (int)((m / p.W) % p.H);
+                const bool ok = c_tap_ok[par] && (unsigned)(yy + c_dy[par]) < (unsigned)p.H && (unsigned)(xx + c_dx[par]) < (unsigned)p.W;
+                glds16(a_ok[par] ? p.a + m * p.lda + n0 + csrc : tn_zero_block + (lchunk & 3) * 4, As + (4 * i + wave) * 256);
+                glds16(ok ? p.b + (m + c_shift[par]) * p.ldb + c_ci[par] : tn_zero_block + (lchunk & 3) * 4, Bs + (4 * i + wave) * 256);
+            } else {
+                glds16(p.a + (mbase + row) * p.lda + n0 + csrc, As + (4 * i + wave) * 256);
+                glds16(p.b + (mbase + row) * p.ldb + k0 + csrc, Bs + (4 * i + wave) * 256);
+            }
         }
     };
 
@@ -150,11 +183,43 @@ extern "C" int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, lo
     LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_gemm_tn_f32: grid too large");
     constexpr size_t smem = 2ull * STAGE * sizeof(float);
     static LdmLdsOptIn opt_in;
-    (void)opt_in((const void *)gemm_tn_kernel, smem);
+    (void)opt_in((const void *)gemm_tn_kernel<false>, smem);
     void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)N * K, (hipStream_t)stream,
                                4.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_gemm_tn_f32");
+    return LDM_OK;
+}
+
+// Weight gradient of a dense 3x3 conv (zero pad 1: vae.py:57-58 and its autograd) WITHOUT the im2col matrix:
+//   out[s][n][tap * Cin + ci] = sum over the pixels m of split s of dy[m][n] * x[pixel m shifted by tap][ci]
+// dy [M = B*H*W, Cout] (row stride lda), x [M, Cin] rows; out is [splits][Npad][Kpad] with Npad = Cout rounded up to 128 and Kpad = 9 * Cin
+// rounded up to 128 (rows >= Cout and columns >= 9 * Cin come out as zeros); the caller sums the split planes (ldm_reduce_partials_f32) and
+// takes the [Cout][9 * Cin] corner.  colsum_dy: optional [splits][Npad] column sums of dy (the bias gradient).  Cin % 4 == 0.
+extern "C" int ldm_conv3x3_wgrad_f32(const float *dy, long long lda, const float *x, float *out, float *colsum_dy, int B, int H, int W, int Cin, int Cout,
+                                     int splits, void *stream)
+{
+    LDM_REQUIRE(dy && x && out, "ldm_conv3x3_wgrad_f32: null pointer");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0 && lda >= Cout && lda % 4 == 0, "ldm_conv3x3_wgrad_f32: bad shape");
+    const long long M = (long long)B * H * W;
+    LDM_REQUIRE(M < (1ll << 31) && splits >= 1 && M % splits == 0 && (M / splits) % BR == 0,
+                "ldm_conv3x3_wgrad_f32: B*H*W=%lld must split into %d runs of a multiple of 32 pixels", M, splits);
+    LDM_REQUIRE(ldm_aligned16(dy) && ldm_aligned16(x) && (((size_t)out) & 7) == 0 && (((size_t)colsum_dy) & 7) == 0, "ldm_conv3x3_wgrad_f32: unaligned pointer");
+    TnP p{};
+    const int Np = (Cout + BT - 1) / BT * BT, Kp = (9 * Cin + BT - 1) / BT * BT;
+    p.a = dy; p.b = x; p.out = out; p.colsum = colsum_dy; p.lda = lda; p.ldb = Cin; p.M = (int)M; p.N = Np; p.K = Kp; p.ms = (int)(M / splits); p.splits = splits;
+    p.ntn = Np / BT; p.ntk = Kp / BT;
+    p.H = H; p.W = W; p.Cin = Cin; p.Nreal = Cout;
+    const long long blocks = (long long)p.ntn * p.ntk * splits;
+    LDM_REQUIRE(blocks <= 0x7fffffffLL, "ldm_conv3x3_wgrad_f32: grid too large");
+    constexpr size_t smem = 2ull * STAGE * sizeof(float);
+    static LdmLdsOptIn opt_in;
+    (void)opt_in((const void *)gemm_tn_kernel<true>, smem);
+    void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)Cout * 9.0 * Cin, (hipStream_t)stream,
+                               4.0 * M * ((double)Cout + Cin) + 4.0 * Np * (double)Kp * splits);
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
+    ldm_prof_end(rec, (hipStream_t)stream);
+    LDM_CHECK_LAUNCH("ldm_conv3x3_wgrad_f32");
     return LDM_OK;
 }

@@ -650,3 +650,29 @@ def gconv3x3_bf16_tiled(v):
 def gemm_tn_ring(v):
     """1 (default): gemm_tn_bf16 on 256 x 256 tiles (one workgroup per CU) where the shape allows; 0: the 128-row kernel.  Returns the old value."""
     return _lib.load().ldm_gemm_tn_ring(v)
+
+
+def conv3x3_wgrad(dy, x, B, H, W, cin, cout, want_colsum=True):
+    """(dW [cout, 9 * cin] fp32 with columns (tap, ci), column sums of dy [cout] or None) of a dense 3x3 conv (zero pad 1) from the
+    gradient rows dy [B*H*W, cout] and the input rows x [B*H*W, cin]: implicit im2col inside the weight-gradient GEMM."""
+    m = B * H * W
+    npad, kpad = (cout + 127) // 128 * 128, (9 * cin + 127) // 128 * 128
+    tiles = (npad // 128) * (kpad // 128)
+    s = 1
+    while tiles * s < 512 and m % (2 * s) == 0 and (m // (2 * s)) % 32 == 0 and m // (2 * s) >= 256 and s < 512:
+        s *= 2
+    dev = dy.device
+    parts = torch.empty(s, npad, kpad, device=dev, dtype=torch.float32)
+    cs = torch.empty(s, npad, device=dev, dtype=torch.float32) if want_colsum else None
+    _call("ldm_conv3x3_wgrad_f32", _dev(dy, "dy"), dy.shape[1], _dev(x, "x"), _dev(parts, "parts"), _opt(cs, "colsum"), B, H, W, cin, cout, s)
+    if s == 1:
+        full, csum = parts[0], (cs[0] if want_colsum else None)
+    else:
+        full = torch.empty(npad, kpad, device=dev, dtype=torch.float32)
+        if want_colsum:
+            csum = torch.empty(npad, device=dev, dtype=torch.float32)
+            reduce_partials_pair(parts, npad * kpad, full, cs, npad, csum, s)
+        else:
+            csum = None
+            reduce_partials(parts, s, npad * kpad, full)
+    return full[:cout, :9 * cin], (csum[:cout] if want_colsum else None)

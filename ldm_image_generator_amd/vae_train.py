@@ -18,6 +18,7 @@ from .modules import w2d
 from .train import _Rows, grad_weight_rows
 
 SLOPE = 0.01            # F.leaky_relu's default negative_slope (vae.py:62,64)
+IMPLICIT_WGRAD = True   # dense 3x3 weight gradients without the im2col matrix (False: explicit im2col + TN / NT GEMM, the round-2 form)
 
 
 def _pack3x3(w):        # [Cout, Cin, 3, 3] -> [Cout][tap][Cin]
@@ -40,6 +41,13 @@ def _conv_grads(dy, x, shape, conv, grads):
     """weight / bias gradient of one dense 3x3 conv from the gradient at its pre-activation and its input rows."""
     b, h, w = shape
     cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+    if IMPLICIT_WGRAD and cin % 4 == 0 and cout % 4 == 0 and dy.shape[0] % 32 == 0:
+        # implicit im2col inside the weight-gradient GEMM (ldm_conv3x3_wgrad_f32): the explicit matrix is 9x the activation
+        # (1.2 GB per conv at 256 x 256, batch 8, C = 64) written once and read once
+        dw, db = ops.conv3x3_wgrad(dy, x, b, h, w, cin, cout)
+        grads[conv.weight] = dw.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+        grads[conv.bias] = db.contiguous()
+        return
     dyr = _Rows(dy)
     dw = grad_weight_rows(dyr, _Rows(ops.im2col3x3(x, b, h, w, cin)), dy.shape[0])          # [Cout, 9 Cin]
     grads[conv.weight] = dw.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
