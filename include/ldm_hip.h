@@ -345,6 +345,12 @@ int ldm_channelnorm_film_bf16(const float *x, const float *film, const int *slot
  * dfilm (mul | bias) [B*HW, 2C] written once as bf16 */
 int ldm_channelnorm_film_bwd_bf16(const float *x, const float *film, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
                                   void *dfilm_bf16, int B, int HW, int C, float eps, void *stream);
+/* ldm_channelnorm_film_bf16 / ldm_channelnorm_film_bwd_bf16 with the FiLM rows themselves in bf16 ([nslot, HW, 2C] bf16, widened exactly on
+ * load): the bf16 training step keeps its per-(sample, pixel) FiLM rows as the bf16 output of the proj2 GEMM */
+int ldm_channelnorm_film16_bf16(const float *x, const void *film_bf16, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
+                                void *stream);
+int ldm_channelnorm_film16_bwd_bf16(const float *x, const void *film_bf16, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
+                                    void *dfilm_bf16, int B, int HW, int C, float eps, void *stream);
 
 /* Encodings.proj1 in separable form for the training step (unet.py:18-20 with one timestep per sample): the input of proj1 is
  * cat[pe(pixel), te(t_b)], so proj1(cat) = P[pixel] + T[b] with P = W1[:, :C] pe [HW, N] and T = W1[:, C:] te + b1 [B, N]

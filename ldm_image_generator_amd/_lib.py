@@ -160,6 +160,8 @@ SIGNATURES = {
     "ldm_relu_bwd_bf16": (_I, [_P, _P, _P, _L, _P]),
     "ldm_channelnorm_film_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_channelnorm_film_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_channelnorm_film16_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ldm_channelnorm_film16_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ldm_gconv3x3_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_gconv3x3_bf16_tiled": (_I, [_I]),
     "ldm_gconv3x3_wgrad_bf16_splits": (_I, [_I, _I, _I, _I]),

@@ -118,8 +118,21 @@ __global__ void relu_bwd_bf16_kernel(const u32x4 *__restrict__ dy, const u32x4 *
 // ---- ChannelNorm + FiLM, forward: fp32 in, fp32 and/or bf16 out ----------------------------------------------------------------
 // NV float4 per lane and R row groups per wave (see channelnorm_film_rows_kernel in elementwise.hip: the loads of all R rows are in
 // flight before the first reduction; arithmetic and its order do not depend on NV / R)
-template <int NV, int R>
-__global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *__restrict__ x, const float *__restrict__ film, const int *__restrict__ slot,
+// four FiLM values (chunk c4 of a row) from fp32 rows or -- FBF: the bf16 training step keeps its per-(sample, pixel) FiLM rows in bf16 --
+// from bf16 rows widened exactly
+template <bool FBF>
+__device__ __forceinline__ f32x4 film4(const void *row, int c4)
+{
+    if constexpr (FBF) {
+        const u32x2 w = ((const u32x2 *)row)[c4];
+        return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u)};
+    } else {
+        return ((const f32x4 *)row)[c4];
+    }
+}
+
+template <int NV, int R, bool FBF = false>
+__global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *__restrict__ x, const void *__restrict__ film, const int *__restrict__ slot,
                                                                   float *__restrict__ out32, unsigned short *__restrict__ out16, long long rows, int HW,
                                                                   int C, float eps, int lpr)
 {
@@ -161,12 +174,12 @@ __global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *_
         if (!live[r]) continue;
         const int b = (int)(row[r] / HW), pix = (int)(row[r] - (long long)b * HW);
         const int sl = slot ? slot[b] : 0;
-        const f32x4 *fr = (const f32x4 *)(film + ((long long)sl * HW + pix) * 2 * C);
+        const void *fr = (const char *)film + ((long long)sl * HW + pix) * 2 * C * (FBF ? 2 : 4);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c4 = sub + i * lpr;
             if (c4 < c4n) {
-                const f32x4 mu = fr[c4], bi = fr[c4n + c4];
+                const f32x4 mu = film4<FBF>(fr, c4), bi = film4<FBF>(fr, c4n + c4);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn((v[r][i][e] - mean) / den, mu[e]), bi[e]);
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(256) void channelnorm_film_mp_kernel(const float *_
 
 // backward (one FiLM slot per sample: every (slot, pixel) row of dfilm has exactly one writer):
 //   dfilm = (dxf * xn | dxf) as bf16;  dx = dres + (dxn - mean(dxn) - xn * sum(dxn * xn) / (C - 1)) / den, dxn = dxf * mul;  dx16 = bf16(dx)
-__global__ __launch_bounds__(256) void channelnorm_film_bwd_mp_kernel(const float *__restrict__ x, const float *__restrict__ film, const int *__restrict__ slot,
+template <bool FBF>
+__global__ __launch_bounds__(256) void channelnorm_film_bwd_mp_kernel(const float *__restrict__ x, const void *__restrict__ film, const int *__restrict__ slot,
                                                                       const float *__restrict__ dxf, const float *__restrict__ dres, float *__restrict__ dx,
                                                                       unsigned short *__restrict__ dx16, unsigned short *__restrict__ dfilm16, long long rows,
                                                                       int HW, int C, float eps, int lpr)
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(256) void channelnorm_film_bwd_mp_kernel(const floa
     const int b = (int)(rr / HW), pix = (int)(rr - (long long)b * HW);
     const int sl = slot ? slot[b] : 0;
     const long long frow = ((long long)sl * HW + pix) * 2 * C;
-    const f32x4 *fr = (const f32x4 *)(film + frow);
+    const void *fr = (const char *)film + frow * (FBF ? 2 : 4);
     f32x4 v[kMaxV], g[kMaxV];
     float s = 0.f;
 #pragma unroll
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(256) void channelnorm_film_bwd_mp_kernel(const floa
     for (int i = 0; i < kMaxV; ++i) {
         const int c4 = sub + i * lpr;
         if (c4 < c4n) {
-            const f32x4 mu = live ? fr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 mu = live ? film4<FBF>(fr, c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 gm;
             const f32x4 gx4 = g[i];
 #pragma unroll
@@ -312,8 +326,24 @@ extern "C" int ldm_relu_bwd_bf16(const void *dy, const void *y, void *dx, long l
     LDM_BF16_ELEMENTWISE("ldm_relu_bwd_bf16", relu_bwd_bf16_kernel, (const u32x4 *)dy, (const u32x4 *)y, (u32x4 *)dx, n / 8)
 }
 
+static int channelnorm_film_bf16_impl(const float *x, const void *film, bool film16, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
+                                      void *stream);
+
 extern "C" int ldm_channelnorm_film_bf16(const float *x, const float *film, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
                                          void *stream)
+{
+    return channelnorm_film_bf16_impl(x, film, false, slot, out_f32, out_bf16, B, HW, C, eps, stream);
+}
+
+// the same with the FiLM rows themselves in bf16 ([nslot, HW, 2C] bf16: the bf16 training step's per-(sample, pixel) rows)
+extern "C" int ldm_channelnorm_film16_bf16(const float *x, const void *film_bf16, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
+                                           void *stream)
+{
+    return channelnorm_film_bf16_impl(x, film_bf16, true, slot, out_f32, out_bf16, B, HW, C, eps, stream);
+}
+
+static int channelnorm_film_bf16_impl(const float *x, const void *film, bool film16, const int *slot, float *out_f32, void *out_bf16, int B, int HW, int C, float eps,
+                                      void *stream)
 {
     LDM_REQUIRE(x && film && (out_f32 || out_bf16), "ldm_channelnorm_film_bf16: null pointer");
     LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_bf16: bad shape B=%d HW=%d C=%d", B, HW, C);
@@ -325,8 +355,14 @@ extern "C" int ldm_channelnorm_film_bf16(const float *x, const float *film, cons
     const int r = (nv <= 2 && waves >= 4 * 16384) ? 4 : 1;                 // as launch_channelnorm_film (elementwise.hip)
     const dim3 grid(blocks_for((waves + r - 1) / r, 4));
 #define LDM_CNF16_LAUNCH(NV_, R_)                                                                                                      \
-    hipLaunchKernelGGL((channelnorm_film_mp_kernel<NV_, R_>), grid, dim3(256), 0, (hipStream_t)stream, x, film, slot, out_f32,        \
-                       (unsigned short *)out_bf16, rows, HW, C, eps, lpr)
+    do {                                                                                                                               \
+        if (film16)                                                                                                                    \
+            hipLaunchKernelGGL((channelnorm_film_mp_kernel<NV_, R_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, film, slot, out_f32, \
+                               (unsigned short *)out_bf16, rows, HW, C, eps, lpr);                                                     \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((channelnorm_film_mp_kernel<NV_, R_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, film, slot, out_f32, \
+                               (unsigned short *)out_bf16, rows, HW, C, eps, lpr);                                                     \
+    } while (0)
     if (nv == 1 && r == 4) LDM_CNF16_LAUNCH(1, 4);
     else if (nv == 2 && r == 4) LDM_CNF16_LAUNCH(2, 4);
     else if (nv == 1) LDM_CNF16_LAUNCH(1, 1);
@@ -338,16 +374,35 @@ extern "C" int ldm_channelnorm_film_bf16(const float *x, const float *film, cons
     return LDM_OK;
 }
 
+static int channelnorm_film_bwd_bf16_impl(const float *x, const void *film, bool film16, const int *slot, const float *dxf, const float *dres, float *dx,
+                                          void *dx_bf16, void *dfilm_bf16, int B, int HW, int C, float eps, void *stream);
+
 extern "C" int ldm_channelnorm_film_bwd_bf16(const float *x, const float *film, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
                                              void *dfilm_bf16, int B, int HW, int C, float eps, void *stream)
+{
+    return channelnorm_film_bwd_bf16_impl(x, film, false, slot, dxf, dres, dx, dx_bf16, dfilm_bf16, B, HW, C, eps, stream);
+}
+
+extern "C" int ldm_channelnorm_film16_bwd_bf16(const float *x, const void *film_bf16, const int *slot, const float *dxf, const float *dres, float *dx, void *dx_bf16,
+                                               void *dfilm_bf16, int B, int HW, int C, float eps, void *stream)
+{
+    return channelnorm_film_bwd_bf16_impl(x, film_bf16, true, slot, dxf, dres, dx, dx_bf16, dfilm_bf16, B, HW, C, eps, stream);
+}
+
+static int channelnorm_film_bwd_bf16_impl(const float *x, const void *film, bool film16, const int *slot, const float *dxf, const float *dres, float *dx,
+                                          void *dx_bf16, void *dfilm_bf16, int B, int HW, int C, float eps, void *stream)
 {
     LDM_REQUIRE(x && film && dxf && dx && dfilm_bf16, "ldm_channelnorm_film_bwd_bf16: null pointer");
     LDM_REQUIRE(B > 0 && HW > 0 && C >= 8 && C % 4 == 0 && C <= 64 * 4 * kMaxV, "ldm_channelnorm_film_bwd_bf16: bad shape");
     const int lpr = pow2_lanes(C / 4);
     const long long rows = (long long)B * HW;
     const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
-    hipLaunchKernelGGL(channelnorm_film_bwd_mp_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, dxf, dres, dx,
-                       (unsigned short *)dx_bf16, (unsigned short *)dfilm_bf16, rows, HW, C, eps, lpr);
+    if (film16)
+        hipLaunchKernelGGL(channelnorm_film_bwd_mp_kernel<true>, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, dxf, dres, dx,
+                           (unsigned short *)dx_bf16, (unsigned short *)dfilm_bf16, rows, HW, C, eps, lpr);
+    else
+        hipLaunchKernelGGL(channelnorm_film_bwd_mp_kernel<false>, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, film, slot, dxf, dres, dx,
+                           (unsigned short *)dx_bf16, (unsigned short *)dfilm_bf16, rows, HW, C, eps, lpr);
     LDM_CHECK_LAUNCH("ldm_channelnorm_film_bwd_bf16");
     return LDM_OK;
 }

@@ -470,12 +470,16 @@ def relu_bwd_bf16(dy, y, dx):
 
 
 def channelnorm_film_bf16(x, film, slot, out_f32, out_bf16, B, HW, C, eps=1e-4):
-    _call("ldm_channelnorm_film_bf16", _dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32), _opt(out_f32, "out_f32"),
-          _opt(out_bf16, "out_bf16", BF16), B, HW, C, eps)
+    """ChannelNorm + FiLM with bf16 (and / or fp32) output; ``film`` rows fp32 or bf16 by their dtype."""
+    f16 = film.dtype == BF16
+    _call("ldm_channelnorm_film16_bf16" if f16 else "ldm_channelnorm_film_bf16", _dev(x, "x"), _dev(film, "film", BF16 if f16 else torch.float32),
+          _opt(slot, "slot", torch.int32), _opt(out_f32, "out_f32"), _opt(out_bf16, "out_bf16", BF16), B, HW, C, eps)
 
 
 def channelnorm_film_bwd_bf16(x, film, slot, dxf, dres, dx, dx_bf16, dfilm_bf16, B, HW, C, eps=1e-4):
-    _call("ldm_channelnorm_film_bwd_bf16", _dev(x, "x"), _dev(film, "film"), _opt(slot, "slot", torch.int32), _dev(dxf, "dxf"), _opt(dres, "dres"),
+    f16 = film.dtype == BF16
+    _call("ldm_channelnorm_film16_bwd_bf16" if f16 else "ldm_channelnorm_film_bwd_bf16", _dev(x, "x"), _dev(film, "film", BF16 if f16 else torch.float32),
+          _opt(slot, "slot", torch.int32), _dev(dxf, "dxf"), _opt(dres, "dres"),
           _dev(dx, "dx"), _opt(dx_bf16, "dx_bf16", BF16), _dev(dfilm_bf16, "dfilm_bf16", BF16), B, HW, C, eps)
     return dx
 

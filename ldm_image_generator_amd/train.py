@@ -350,7 +350,9 @@ def encodings_forward(enc, lc, bf16=False, pt=None):
     m = lc.b * lc.hw
     hid = torch.empty(m, n, device=dev, dtype=BF16 if bf16 else torch.float32)
     ops.film_hidden(p_rows, t_rows, hid, lc.b, lc.hw, n)
-    film = torch.empty(m, 2 * c, device=dev, dtype=torch.float32)
+    # bf16 mode: the per-(sample, pixel) FiLM rows are the proj2 GEMM's bf16 output (written once, read by ChannelNorm forward and
+    # backward: 2 bytes instead of 4 per value each time); FILM_ROWS_BF16 = False keeps them fp32
+    film = torch.empty(m, 2 * c, device=dev, dtype=BF16 if (bf16 and FILM_ROWS_BF16) else torch.float32)
     if bf16:
         ops.gemm_bf16(hid, m, 2 * c, n, [W16.get(enc.proj2.weight)], film, biases=[enc.proj2.bias.detach()])
     else:
@@ -390,6 +392,7 @@ def encodings_backward(enc, lc, hid, dfilm, grads):
 # conv (its three kernels), window attention, stem / head / ch_convs, every parameter gradient and AdamW's master weights.
 # ------------------------------------------------------------------------------------------------------
 PRECISIONS = ("f32", "bf16")
+FILM_ROWS_BF16 = True       # bf16 training mode: FiLM rows [B*HW, 2C] kept as bf16 (one more rounding, of the same size as the one ChannelNorm's output gets)
 BF16 = torch.bfloat16
 
 
