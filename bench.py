@@ -383,7 +383,6 @@ def main():
             for wi in range(args.train_warmup):                                   # warm-up: allocator, RCCL buffers, weight caches, and the
                 ldist.train_step(ddpm, opt, xb, 10000 + wi, world)                # optimizer state of the experts a step happens to pick
             fence()
-            ops.prof_enable(rank == 0)
             tstats = {}
             t0 = time.perf_counter()
             for i in range(args.train_steps):
@@ -392,6 +391,14 @@ def main():
             dts = max_over_ranks(time.perf_counter() - t0)
             leg = {"ms_per_step": dts / args.train_steps * 1e3, "value": args.train_batch * world * args.train_steps / dts,
                    "loss": float(loss.detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            # per-kernel times come from the SAME steps run once more with a hipEvent pair around every MFMA launch (~1 000 events per
+            # step: they cost the bf16 step 1-3 ms, so they stay out of the timed steps, as in the autocast leg); every rank runs them
+            ops.prof_enable(rank == 0)
+            t0 = time.perf_counter()
+            for i in range(args.train_steps):
+                ldist.train_step(ddpm, opt, xb, 1 + i, world)
+            fence()
+            leg["ms_per_step_with_events"] = max_over_ranks(time.perf_counter() - t0) / args.train_steps * 1e3
             if world > 1:                                  # bucketed all-reduce overlapped with the backward (dist.GradSync): what was NOT hidden
                 leg["allreduce_ms_exposed"] = tstats.get("allreduce_ms_exposed")
                 leg["allreduce_bytes_per_step"] = tstats.get("allreduce_bytes")
@@ -469,12 +476,15 @@ def main():
         for _ in range(2):
             vae_iter()
         fence()
-        ops.prof_enable(rank == 0)
         t0 = time.perf_counter()
         for _ in range(args.vae_steps):
             losses = vae_iter()
         fence()
         dtv = max_over_ranks(time.perf_counter() - t0)
+        ops.prof_enable(rank == 0)                       # per-kernel times: the same iterations once more, with hipEvents (see train_step)
+        for _ in range(args.vae_steps):
+            vae_iter()
+        fence()
         vae_step = {"ms_per_step": dtv / args.vae_steps * 1e3, "value": vb * world * args.vae_steps / dtv, "unit": "images/s", "dtype": "f32",
                     "config": {"workload": "train_vae.py iteration: VAE loss + generator hinge backward + AdamW, then Discriminator hinge step + AdamW; "
                                            "images [%d, 3, %d, %d] per GPU, Encoder / Decoder / VectorQuantizer(8192 x 8) / Discriminator at default widths" % (vb, vs, vs),

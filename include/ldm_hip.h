@@ -255,8 +255,11 @@ int ldm_colsum_f32(const float *x, float *out, long long M, int N, int accumulat
 int ldm_transpose_colsum_f32(const float *x, float *out, float *csum, long long R, int Cc, void *stream);
 int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream);        /* split-K sum */
 /* two such sums with the same S in one launch (a weight gradient's partial planes and its bias gradient's); n_a, n_b multiples of 4;
- * each result equals ldm_reduce_partials_f32's bit for bit */
-int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n_a, const float *parts_b, float *out_b, long long n_b, int S, void *stream);
+ * each result equals ldm_reduce_partials_f32's bit for bit.  seg_len_a > 0: sum a is a [n_a / row_len_a, row_len_a] matrix whose column
+ * blocks of seg_len_a belong to different parameters (the c-weights of a block's three ReGLUs, unet.py:20-27): it is stored as
+ * [row_len_a / seg_len_a][rows][seg_len_a], every block a contiguous tensor; 0: plain */
+int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n_a, const float *parts_b, float *out_b, long long n_b, int S,
+                                 long long row_len_a, long long seg_len_a, void *stream);
 /* Weight gradient of a 1x1 conv / Linear WITHOUT transposed copies (autograd of modules.py:10-12, unet.py:20-21,
  * attention in/out projections): out[s][n][k] = sum over rows m of split s of a[m*lda + n] * b[m*ldb + k], i.e.
  * dW = dY^T X with the pixel rows as the contraction.  N, K multiples of 128; M / splits a multiple of 32; the caller

@@ -130,7 +130,7 @@ SIGNATURES = {
     "ldm_colsum_f32": (_I, [_P, _P, _L, _I, _I, _P]),
     "ldm_transpose_colsum_f32": (_I, [_P, _P, _P, _L, _I, _P]),
     "ldm_reduce_partials_f32": (_I, [_P, _P, _I, _L, _P]),
-    "ldm_reduce_partials_pair_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _P]),
+    "ldm_reduce_partials_pair_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _L, _L, _P]),
     "ldm_gconv3x3_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_gemm_tn_f32": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_conv3x3_wgrad_f32": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -95,7 +95,10 @@ __global__ void reduce_partials_kernel(const float *__restrict__ parts, float *_
 // in plane order.  Fixed association ((q0 + q1) + q2) + q3, no atomics: the result does not depend on scheduling.  The scalar
 // kernel above had one dependent 4-byte load chain per element: 15 us per launch on average over the ~330 weight-gradient
 // reductions of a training step (S = 4 ... 128 planes of 50 k ... 3 M elements), most of it latency.
-__device__ __forceinline__ void reduce_partials_v4_body(const f32x4 *__restrict__ parts, f32x4 *__restrict__ out, int S, long long n4, long long block)
+// row4 / seg4 (optional, float4 units): the summed [rows, row4] matrix is stored as [row4 / seg4][rows][seg4] -- the column blocks of
+// a weight gradient that belongs to several parameters (the c-weights of the three ReGLUs of a block) land as contiguous tensors
+__device__ __forceinline__ void reduce_partials_v4_body(const f32x4 *__restrict__ parts, f32x4 *__restrict__ out, int S, long long n4, long long block,
+                                                        long long row4 = 0, long long seg4 = 0)
 {
     __shared__ f32x4 part[3][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -125,7 +128,12 @@ __device__ __forceinline__ void reduce_partials_v4_body(const f32x4 *__restrict_
         acc += part[0][lane];
         acc += part[1][lane];
         acc += part[2][lane];
-        out[i] = acc;
+        long long dst = i;
+        if (seg4) {
+            const long long row = i / row4, k4 = i - row * row4, e = k4 / seg4;
+            dst = e * (n4 / row4) * seg4 + row * seg4 + (k4 - e * seg4);
+        }
+        out[dst] = acc;
     }
 }
 
@@ -136,9 +144,10 @@ __global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const f32x4 *__
 
 // two sums with the same S in one launch (a weight gradient's planes and its bias gradient's): blocks [0, blocks_a) take job a
 __global__ __launch_bounds__(256) void reduce_partials_pair_kernel(const f32x4 *__restrict__ pa, f32x4 *__restrict__ oa, long long na4, unsigned blocks_a,
-                                                                   const f32x4 *__restrict__ pb, f32x4 *__restrict__ ob, long long nb4, int S)
+                                                                   const f32x4 *__restrict__ pb, f32x4 *__restrict__ ob, long long nb4, int S,
+                                                                   long long row4, long long seg4)
 {
-    if (blockIdx.x < blocks_a) reduce_partials_v4_body(pa, oa, S, na4, blockIdx.x);
+    if (blockIdx.x < blocks_a) reduce_partials_v4_body(pa, oa, S, na4, blockIdx.x, row4, seg4);
     else reduce_partials_v4_body(pb, ob, S, nb4, blockIdx.x - blocks_a);
 }
 
@@ -1592,14 +1601,16 @@ extern "C" int ldm_reduce_partials_f32(const float *parts, float *out, int S, lo
 }
 
 extern "C" int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n_a, const float *parts_b, float *out_b, long long n_b,
-                                           int S, void *stream)
+                                           int S, long long row_len_a, long long seg_len_a, void *stream)
 {
     LDM_REQUIRE(parts_a && out_a && parts_b && out_b && S > 0 && n_a > 0 && n_b > 0, "ldm_reduce_partials_pair_f32: bad arguments");
+    LDM_REQUIRE(seg_len_a == 0 || (seg_len_a > 0 && seg_len_a % 4 == 0 && row_len_a > 0 && row_len_a % seg_len_a == 0 && n_a % row_len_a == 0 && parts_a != out_a),
+                "ldm_reduce_partials_pair_f32: column segments must be multiples of 4 that divide the row, the row must divide n_a, no in-place");
     LDM_REQUIRE(n_a % 4 == 0 && n_b % 4 == 0, "ldm_reduce_partials_pair_f32: element counts must be multiples of 4");
     LDM_REQUIRE(ldm_aligned16(parts_a) && ldm_aligned16(out_a) && ldm_aligned16(parts_b) && ldm_aligned16(out_b), "ldm_reduce_partials_pair_f32: unaligned pointer");
     const unsigned ba = blocks_for(n_a / 4, 64), bb = blocks_for(n_b / 4, 64);
     hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3(ba + bb), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)parts_a, (f32x4 *)out_a, n_a / 4, ba,
-                       (const f32x4 *)parts_b, (f32x4 *)out_b, n_b / 4, S);
+                       (const f32x4 *)parts_b, (f32x4 *)out_b, n_b / 4, S, seg_len_a ? row_len_a / 4 : 0, seg_len_a / 4);
     LDM_CHECK_LAUNCH("ldm_reduce_partials_pair_f32");
     return LDM_OK;
 }

@@ -297,13 +297,16 @@ def reduce_partials(parts, S, n, out):
     return out
 
 
-def reduce_partials_pair(parts_a, n_a, out_a, parts_b, n_b, out_b, S):
-    """reduce_partials twice (same S) in one launch; falls back to two launches when a count is not a multiple of 4."""
-    if n_a % 4 or n_b % 4:
+def reduce_partials_pair(parts_a, n_a, out_a, parts_b, n_b, out_b, S, row_len_a=0, seg_len_a=0):
+    """reduce_partials twice (same S) in one launch; falls back to two launches when a count is not a multiple of 4.
+    ``seg_len_a`` > 0: sum a, a [n_a / row_len_a, row_len_a] matrix, is stored as [row_len_a / seg_len_a][rows][seg_len_a]
+    (contiguous column blocks: gradients of several parameters out of one weight-gradient GEMM)."""
+    if (n_a % 4 or n_b % 4) and not seg_len_a:
         reduce_partials(parts_a, S, n_a, out_a)
         reduce_partials(parts_b, S, n_b, out_b)
     else:
-        _call("ldm_reduce_partials_pair_f32", _dev(parts_a, "parts_a"), _dev(out_a, "out_a"), n_a, _dev(parts_b, "parts_b"), _dev(out_b, "out_b"), n_b, S)
+        _call("ldm_reduce_partials_pair_f32", _dev(parts_a, "parts_a"), _dev(out_a, "out_a"), n_a, _dev(parts_b, "parts_b"), _dev(out_b, "out_b"), n_b, S,
+              row_len_a, seg_len_a)
     return out_a, out_b
 
 

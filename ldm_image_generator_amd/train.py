@@ -534,30 +534,42 @@ def tn16_splits(n_out, k_out, m_red):
     return s
 
 
-def grad_weight_rows16(dy16, x16, m_red, want_colsum=True):
+def grad_weight_rows16(dy16, x16, m_red, want_colsum=True, col_blocks=1):
     """(dW [N, K] fp32, column sums of dy [N] fp32 or None) for bf16 row-major dy [M, N], x [M, K]: the TN bf16 kernel with the
     operands as they lie in memory; layers it does not cover (N or K not a multiple of 128, M not a multiple of 64: tiny test
-    nets) are up-cast and take the fp32 route."""
+    nets) are up-cast and take the fp32 route.  ``col_blocks`` > 1: dW comes back as that many [N, K / col_blocks] column blocks
+    (gradients of separate parameters) -- contiguous tensors straight out of the split sum where there is one, views otherwise."""
     n_out, k_out = dy16.shape[1], x16.shape[1]
     dev = dy16.device
+
+    def blocks(dw):
+        if col_blocks == 1:
+            return dw
+        kb = k_out // col_blocks
+        return [dw[:, e * kb:(e + 1) * kb] for e in range(col_blocks)]
+
     if n_out % 128 or k_out % 128 or m_red % 64:
         dy_r = _Rows(_uncast(dy16))
         dw = grad_weight_rows(dy_r, _Rows(_uncast(x16)), m_red)
-        return dw, (dy_r.colsum() if want_colsum else None)
+        return blocks(dw), (dy_r.colsum() if want_colsum else None)
     s = tn16_splits(n_out, k_out, m_red)
     out = torch.empty(n_out, k_out, device=dev, dtype=torch.float32)
     cs = torch.empty(s, n_out, device=dev, dtype=torch.float32) if want_colsum else None
     if s == 1:
         ops.gemm_tn_bf16(dy16, x16, out, m_red, n_out, k_out, 1, colsum=cs)
-        return out, (cs[0] if want_colsum else None)
+        return blocks(out), (cs[0] if want_colsum else None)
     parts = torch.empty(s, n_out, k_out, device=dev, dtype=torch.float32)
     ops.gemm_tn_bf16(dy16, x16, parts, m_red, n_out, k_out, s, colsum=cs)
     if want_colsum:                                             # both sums in one launch
         csum = torch.empty(n_out, device=dev, dtype=torch.float32)
+        if col_blocks > 1 and (k_out // col_blocks) % 4 == 0:
+            out3 = out.view(col_blocks, n_out, k_out // col_blocks)
+            ops.reduce_partials_pair(parts, n_out * k_out, out3, cs, n_out, csum, s, row_len_a=k_out, seg_len_a=k_out // col_blocks)
+            return [out3[e] for e in range(col_blocks)], csum
         ops.reduce_partials_pair(parts, n_out * k_out, out, cs, n_out, csum, s)
-        return out, csum
+        return blocks(out), csum
     ops.reduce_partials(parts, s, n_out * k_out, out)
-    return out, None
+    return blocks(out), None
 
 
 def block_forward16(blk, rows, shape, ctx, picks, film, codes16, enc_hidden16):
@@ -603,7 +615,7 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     regs = sv["regs"]
     f = regs[0].a.weight.shape[0]
     # ---- RandomMoE ------------------------------------------------------------------------------------
-    dwc, bias_dy = grad_weight_rows16(dy16, sv["hid"], m)            # [C, 3F], [C]
+    dwc, bias_dy = grad_weight_rows16(dy16, sv["hid"], m, col_blocks=3)   # three [C, F] blocks of [C, 3F], [C]
     da, db = _e16(m, 3 * f, dev=dev), _e16(m, 3 * f, dev=dev)
     # dhid = dy . Wc with the gate's backward in the epilogue: dhid never reaches HBM
     ops.gemm_bf16_gate_bwd(dy16, m, 3 * f, c, [W16.get(r.c.weight, True) for r in regs], sv["a_pre"], sv["b_pre"], da, db)
@@ -616,7 +628,7 @@ def block_backward16(sv, dy, dy16, ctx, grads):
     # separate rows (one launch) so that no two parameters share gradient storage
     brows = ops.replicate(bias_dy, 4 + int(blk.attention_flag))
     for e, r in enumerate(regs):
-        grads.add(r.c.weight, dwc[:, e * f:(e + 1) * f])
+        grads.add(r.c.weight, dwc[e])
         grads.add(r.c.bias, brows[e])
         grads.add(r.a.weight, dwa[e * f:(e + 1) * f])
         grads.add(r.b.weight, dwb[e * f:(e + 1) * f])
@@ -849,7 +861,11 @@ class UNetFunction(torch.autograd.Function):
         if sync is not None:
             flush()
             sync.finish()                                    # averaged gradients are written back into grads.g
-        return (None, dx, None) + tuple(grads.g.get(p) for p in params)
+        # the returned tuple holds the ONLY references to the gradient tensors: autograd's AccumulateGrad then adopts them as .grad
+        # instead of cloning each one (190 copies per step at the default widths)
+        out = tuple(grads.g.get(p) for p in params)
+        grads.g.clear()
+        return (None, dx, None) + out
 
 
 class L1LossFunction(torch.autograd.Function):

@@ -75,6 +75,25 @@ def test_reduce_partials_pair_equals_two_single_launches(gpu_device, S, na, nb):
     assert torch.equal(oa, ra) and torch.equal(ob, rb)
 
 
+@pytest.mark.parametrize("S,rows,row_len,seg", [(2, 128, 384, 128), (5, 96, 48, 16), (16, 1024, 3072, 1024), (3, 8, 24, 4)])
+def test_reduce_partials_pair_column_blocks(gpu_device, S, rows, row_len, seg):
+    """seg_len_a: the summed [rows, row_len] matrix comes back as contiguous [row_len / seg][rows][seg] column blocks (the c-weight
+    gradients of a block's three ReGLUs out of one weight-gradient GEMM), the same bits as slicing the plain sum."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(S + rows)
+    na, nb = rows * row_len, rows
+    pa, pb = torch.randn(S, na, generator=g).cuda(), torch.randn(S, nb, generator=g).cuda()
+    plain, ob = torch.empty(rows, row_len, device=gpu_device), torch.empty(nb, device=gpu_device)
+    ops.reduce_partials_pair(pa, na, plain, pb, nb, ob, S)
+    blocks, ob2 = torch.full((row_len // seg, rows, seg), float("nan"), device=gpu_device), torch.empty(nb, device=gpu_device)
+    ops.reduce_partials_pair(pa, na, blocks, pb, nb, ob2, S, row_len_a=row_len, seg_len_a=seg)
+    assert torch.equal(ob, ob2)
+    for e in range(row_len // seg):
+        assert torch.equal(blocks[e], plain[:, e * seg:(e + 1) * seg])
+    with pytest.raises(RuntimeError):
+        ops.reduce_partials_pair(pa, na, blocks, pb, nb, ob2, S, row_len_a=row_len, seg_len_a=seg + 2)
+
+
 @pytest.mark.parametrize("B,H,W,C,S", [(2, 8, 8, 64, 1), (4, 16, 16, 128, 2), (32, 4, 4, 256, 4), (1, 6, 64, 32, 1), (3, 32, 32, 64, 8)])
 def test_grouped_conv_weight_gradient_kernel(gpu_device, B, H, W, C, S):
     """dW of the 32-per-group 3x3 conv from the row-major activations (no transposed im2col) vs autograd."""
