@@ -583,13 +583,13 @@ int ldm_gconv3x3_dispatch(const GemmP &p, int groups, bool gate, int amode, hipS
         const bool wide = g_gconv_wide && smem_w <= 160 * 1024 && ldm_aligned16(p.out) && p.ldo % 4 == 0 && p.o_gstride % 4 == 0 &&
                           (!p.addend || (ldm_aligned16(p.addend) && p.ldadd % 4 == 0));
         if (wide)
-            hipLaunchKernelGGL(gconv3x3_pipe_kernel<true>, dim3(grid), dim3(NW * 64), smem_w, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
+            ldm_launch(gconv3x3_pipe_kernel<true>, dim3(grid), dim3(NW * 64), smem_w, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
                                1.0f / (float)p.H);
         else
-            hipLaunchKernelGGL(gconv3x3_pipe_kernel<false>, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
+            ldm_launch(gconv3x3_pipe_kernel<false>, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk, 1.0f / (float)p.W,
                                1.0f / (float)p.H);
     } else
-        hipLaunchKernelGGL(gconv3x3_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
+        ldm_launch(gconv3x3_kernel, dim3(grid), dim3(NW * 64), smem, st, p, ntm, (int)total, chunk);
     return 1;
 }
 
@@ -607,7 +607,7 @@ extern "C" int ldm_gconv3x3_wgrad_f32(const float *x, const float *dy, float *ou
     (void)opt_in((const void *)gconv3x3_wgrad_kernel, 80 * 1024);
     void *rec = ldm_prof_begin(LDM_PROF_GCONV_WG, 2.0 * (double)M * C * 288.0, (hipStream_t)stream,
                                8.0 * (double)M * C + 4.0 * splits * (double)C * 288.0);
-    hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(C / 32, splits), dim3(256), smem, (hipStream_t)stream, x, dy, out_planes, (int)M, H, W, C,
+    ldm_launch(gconv3x3_wgrad_kernel, dim3(C / 32, splits), dim3(256), smem, (hipStream_t)stream, x, dy, out_planes, (int)M, H, W, C,
                        (int)(M / splits), 1.0f / (float)W, 1.0f / (float)H);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_gconv3x3_wgrad_f32");

@@ -207,13 +207,13 @@ extern "C" int ldm_gconv3x3_bf16(const void *x, const void *w, const float *bias
         if (total_tiles < 0x7fffffffLL && opt_in((const void *)gconv3x3_bf16_tiled_kernel, smem)) {
             long long grid = (long long)cus * 3;
             if (grid > items) grid = items;
-            hipLaunchKernelGGL(gconv3x3_bf16_tiled_kernel, dim3((unsigned)grid), dim3(256), smem, st, p, R, wshift, tiles_per_image, (int)total_tiles);
+            ldm_launch(gconv3x3_bf16_tiled_kernel, dim3((unsigned)grid), dim3(256), smem, st, p, R, wshift, tiles_per_image, (int)total_tiles);
             ldm_prof_end(rec, st);
             LDM_CHECK_LAUNCH("ldm_gconv3x3_bf16");
             return LDM_OK;
         }
     }
-    hipLaunchKernelGGL(gconv3x3_bf16_kernel, dim3((unsigned)(waves / 4)), dim3(256), 0, st, p);
+    ldm_launch(gconv3x3_bf16_kernel, dim3((unsigned)(waves / 4)), dim3(256), 0, st, p);
     ldm_prof_end(rec, st);
     LDM_CHECK_LAUNCH("ldm_gconv3x3_bf16");
     return LDM_OK;

@@ -131,7 +131,7 @@ extern "C" int ldm_gconv3x3_wgrad_bf16(const void *x, const void *dy, float *out
     (void)opt_in((const void *)gconv3x3_wgrad_bf16_kernel, 150 * 1024);
     hipStream_t st = (hipStream_t)stream;
     void *rec = ldm_prof_begin(LDM_PROF_GCONV_BF16, 2.0 * (double)B * H * W * C * 288.0, st, 4.0 * (double)B * H * W * C + 4.0 * 4 * splits * C * 288.0);
-    hipLaunchKernelGGL(gconv3x3_wgrad_bf16_kernel, dim3(C / 32, splits), dim3(256), smem, st, p);
+    ldm_launch(gconv3x3_wgrad_bf16_kernel, dim3(C / 32, splits), dim3(256), smem, st, p);
     ldm_prof_end(rec, st);
     LDM_CHECK_LAUNCH("ldm_gconv3x3_wgrad_bf16");
     return LDM_OK;

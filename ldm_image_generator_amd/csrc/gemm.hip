@@ -173,7 +173,7 @@ int launch(const GemmP &p, int groups, hipStream_t st)
     (void)opt_in((const void *)kern, smem);
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     dim3 grid(ntm * ntn, groups, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    ldm_launch(kern, grid, dim3(256), smem, st, p);
     return 0;
 }
 
@@ -310,7 +310,7 @@ bool splitk_launch(const ldm_gemm_desc &d, const GemmP &p, bool gate, hipStream_
     e.act = d.act; e.slope = d.slope; e.addend = d.addend; e.ldadd = d.ldadd; e.ldo = d.ldo; e.out = d.out;
     for (int i = 0; i < LDM_MAX_SEG; ++i) { e.bias[i] = p.bias[i]; e.bias2[i] = p.bias2[i]; }
     const long long work = (long long)d.M * (d.N / 4);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, e);
+    ldm_launch(splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, e);
     return true;
 }
 

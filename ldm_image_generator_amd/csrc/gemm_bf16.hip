@@ -420,7 +420,7 @@ void tn_launch(const TnP16 &p, long long blocks, hipStream_t st)
     constexpr size_t smem = (size_t)NS * (1 + KT) * TSUB * sizeof(unsigned short);
     static LdmLdsOptIn opt_in;
     (void)opt_in((const void *)gemm_tn_bf16_kernel<KT>, smem);
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel<KT>, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    ldm_launch(gemm_tn_bf16_kernel<KT>, dim3((unsigned)blocks), dim3(256), smem, st, p);
 }
 
 }  // namespace
@@ -444,7 +444,7 @@ extern "C" int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, lon
     if (g_tn_ring && N % 256 == 0 && K % 256 == 0 && ring_blocks >= (long long)ldm_cu_count() * 3 / 4 && ring_blocks <= 0x7fffffffLL &&
         ring_opt((const void *)gemm_tn_bf16_ring_kernel, ring_smem)) {
         p.ntn = N / 256; p.ntk = K / 256;
-        hipLaunchKernelGGL(gemm_tn_bf16_ring_kernel, dim3((unsigned)ring_blocks), dim3(512), ring_smem, (hipStream_t)stream, p);
+        ldm_launch(gemm_tn_bf16_ring_kernel, dim3((unsigned)ring_blocks), dim3(512), ring_smem, (hipStream_t)stream, p);
         ldm_prof_end(rec, (hipStream_t)stream);
         LDM_CHECK_LAUNCH("ldm_gemm_tn_bf16");
         return LDM_OK;

@@ -468,7 +468,7 @@ int ring_launch(const GemmP &p, hipStream_t st)
     int grid = total < cus ? total : cus;
     if (g_ring == 3 && grid > 8) grid = 8;
     if (grid > 8) grid &= ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), RSMEM, st, p, ntm, ntn, total);
+    ldm_launch(kern, dim3(grid), dim3(512), RSMEM, st, p, ntm, ntn, total);
     return 1;
 }
 

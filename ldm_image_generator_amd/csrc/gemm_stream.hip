@@ -443,7 +443,7 @@ int launch_stream(const GemmP &p, int groups, hipStream_t st)
     if (total > 0x7fffffffLL) return 0;
     int grid = (int)(total < slots ? total : slots);
     if (grid > 8) grid &= ~7;                                          // keep blockIdx % 8 == XCD label across rounds
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p, ntm, ntn, (int)total);
+    ldm_launch(kern, dim3(grid), dim3(256), smem, st, p, ntm, ntn, (int)total);
     return 1;
 }
 

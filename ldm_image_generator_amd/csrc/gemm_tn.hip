@@ -186,7 +186,7 @@ extern "C" int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, lo
     (void)opt_in((const void *)gemm_tn_kernel<false>, smem);
     void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)N * K, (hipStream_t)stream,
                                4.0 * M * ((double)N + K) + 4.0 * N * (double)K * splits);
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
+    ldm_launch(gemm_tn_kernel<false>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_gemm_tn_f32");
     return LDM_OK;
@@ -218,7 +218,7 @@ extern "C" int ldm_conv3x3_wgrad_f32(const float *dy, long long lda, const float
     (void)opt_in((const void *)gemm_tn_kernel<true>, smem);
     void *rec = ldm_prof_begin(LDM_PROF_GEMM_TN, 2.0 * M * (double)Cout * 9.0 * Cin, (hipStream_t)stream,
                                4.0 * M * ((double)Cout + Cin) + 4.0 * Np * (double)Kp * splits);
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
+    ldm_launch(gemm_tn_kernel<true>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, p);
     ldm_prof_end(rec, (hipStream_t)stream);
     LDM_CHECK_LAUNCH("ldm_conv3x3_wgrad_f32");
     return LDM_OK;

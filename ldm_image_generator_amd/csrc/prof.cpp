@@ -1,6 +1,6 @@
-// hipEvent timing of the MFMA kernels for bench.py (include/ldm_hip.h, ldm_prof_*): when enabled, every launch of a
-// profiled entry point is bracketed by two events recorded on ITS stream; reading synchronises the events and sums
-// kernel time and algorithmic FLOPs per kernel class.  Host code only.
+// hipEvent timing of the MFMA kernels for bench.py (include/ldm_hip.h, ldm_prof_*): when enabled, the kernel launch of every
+// profiled entry point carries a (start, stop) event pair bound to its dispatch on ITS stream (hipExtLaunchKernelGGL: common.h,
+// ldm_launch); reading synchronises the events and sums kernel time and algorithmic FLOPs per kernel class.  Host code only.
 #include "common.h"
 #include <mutex>
 #include <vector>
@@ -16,6 +16,7 @@ std::mutex g_mu;
 bool g_on = false;
 std::vector<ProfRec> g_pool;
 size_t g_used = 0;
+constexpr int kVoid = -1000;                 // class of a record whose entry point launched nothing: never summed, never dumped
 
 }  // namespace
 
@@ -32,16 +33,31 @@ void *ldm_prof_begin(int cls, double flops, hipStream_t st, double bytes)
     rec->flops = flops;
     rec->bytes = bytes;
     rec->cls = cls;
-    (void)hipEventRecord(rec->start, st);
+    (void)st;
+    LdmProfPending &pp = ldm_prof_pending();  // the entry's first ldm_launch binds the pair to its dispatch (common.h)
+    pp.start = rec->start;
+    pp.stop = rec->stop;
+    pp.armed = true;
     return (void *)(size_t)(g_used);          // index + 1: the pool may reallocate
 }
 
 void ldm_prof_end(void *h, hipStream_t st)
 {
     if (!h) return;
+    (void)st;
     std::lock_guard<std::mutex> lk(g_mu);
     const size_t i = (size_t)h - 1;
-    if (i < g_used) (void)hipEventRecord(g_pool[i].stop, st);
+    LdmProfPending &pp = ldm_prof_pending();
+    if (pp.armed) {                           // the entry returned without launching (an argument error after the record was opened)
+        pp.armed = false;
+        if (i < g_used) g_pool[i].cls = kVoid;
+    }
+}
+
+LdmProfPending &ldm_prof_pending()
+{
+    static thread_local LdmProfPending pp = {nullptr, nullptr, false};
+    return pp;
 }
 
 static int prof_sum(int cls, long long *launches, double *ms, double *flops, double *bytes = nullptr)
@@ -49,7 +65,7 @@ static int prof_sum(int cls, long long *launches, double *ms, double *flops, dou
     double tms = 0.0, tf = 0.0, tb = 0.0;
     long long n = 0;
     for (size_t i = 0; i < g_used; ++i) {
-        if (cls >= 0 && g_pool[i].cls != cls) continue;
+        if (g_pool[i].cls == kVoid || (cls >= 0 && g_pool[i].cls != cls)) continue;
         float e = 0.f;
         if (hipEventSynchronize(g_pool[i].stop) != hipSuccess || hipEventElapsedTime(&e, g_pool[i].start, g_pool[i].stop) != hipSuccess) {
             ldm_set_error("ldm_prof_read: event %zu not readable", i);
@@ -101,7 +117,8 @@ extern "C" long long ldm_prof_dump(double *out, long long max_records)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     long long n = 0;
-    for (size_t i = 0; i < g_used && n < max_records; ++i, ++n) {
+    for (size_t i = 0; i < g_used && n < max_records; ++i) {
+        if (g_pool[i].cls == kVoid) continue;
         float e = 0.f;
         if (hipEventSynchronize(g_pool[i].stop) != hipSuccess || hipEventElapsedTime(&e, g_pool[i].start, g_pool[i].stop) != hipSuccess) {
             ldm_set_error("ldm_prof_dump: event %zu not readable", i);
@@ -111,6 +128,7 @@ extern "C" long long ldm_prof_dump(double *out, long long max_records)
         out[4 * n + 1] = e;
         out[4 * n + 2] = g_pool[i].flops;
         out[4 * n + 3] = g_pool[i].bytes;
+        ++n;
     }
     return n;
 }
