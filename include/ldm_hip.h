@@ -262,15 +262,19 @@ int ldm_reduce_partials_pair_f32(const float *parts_a, float *out_a, long long n
                                  long long row_len_a, long long seg_len_a, void *stream);
 /* Weight gradient of a 1x1 conv / Linear WITHOUT transposed copies (autograd of modules.py:10-12, unet.py:20-21,
  * attention in/out projections): out[s][n][k] = sum over rows m of split s of a[m*lda + n] * b[m*ldb + k], i.e.
- * dW = dY^T X with the pixel rows as the contraction.  N, K multiples of 128; M / splits a multiple of 32; the caller
+ * dW = dY^T X with the pixel rows as the contraction.  N, K multiples of 128; M a multiple of 32; split s takes rows [s ms, (s + 1) ms)
+ * with ms = M / splits rounded up to a multiple of 32 (the last split takes what is left, at least 32 rows); the caller
  * sums the `splits` partial planes (ldm_reduce_partials_f32) -- fixed order, deterministic.  colsum_a (optional,
  * [splits][N]) receives the column sums of `a` per split: the bias gradient that goes with dW. */
 int ldm_gemm_tn_f32(const float *a, long long lda, const float *b, long long ldb, float *out, float *colsum_a, int M, int N, int K,
                     int splits, void *stream);
 /* Weight gradient of a dense 3x3 conv (zero pad 1; autograd of vae.py:57-58) without the im2col matrix -- the same kernel with an implicit
  * B operand: out[s][n][tap * Cin + ci] = sum over the pixels m of split s of dy[m * lda + n] * x[(pixel m shifted by tap) * Cin + ci].
- * out is [splits][Npad][Kpad], Npad = Cout and Kpad = 9 * Cin rounded up to multiples of 128 (the padding comes out as zeros); the caller
- * sums the planes and takes the [Cout][9 * Cin] corner.  colsum_dy: optional [splits][Npad].  B*H*W / splits a multiple of 32. */
+ * out is [splits][Npad][Kpad], Npad = ldm_conv3x3_wgrad_npad(Cout) (Cout rounded up to the tile height: 32 for Cout <= 32, 64 for Cout <= 64,
+ * else multiples of 128) and Kpad = 9 * Cin rounded up to a multiple of 128 (the padding comes out as zeros); the caller
+ * sums the planes and takes the [Cout][9 * Cin] corner.  colsum_dy: optional [splits][Npad].  B*H*W a multiple of 32; splits as in ldm_gemm_tn_f32
+ * (rows per split rounded up to 32, the last split shorter); H*W <= 2^24. */
+int ldm_conv3x3_wgrad_npad(int Cout);
 int ldm_conv3x3_wgrad_f32(const float *dy, long long lda, const float *x, float *out, float *colsum_dy, int B, int H, int W, int Cin, int Cout,
                           int splits, void *stream);
 /* backward of ldm_channelnorm_film_f32: dx = dres + dnorm(dxf * mul); dfilm (mul | bias) per (slot, pixel): accumulated

@@ -134,6 +134,7 @@ SIGNATURES = {
     "ldm_gconv3x3_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_gemm_tn_f32": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_conv3x3_wgrad_f32": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ldm_conv3x3_wgrad_npad": (_I, [_I]),
     "ldm_channelnorm_film_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "ldm_avgpool2_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_sumpool2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

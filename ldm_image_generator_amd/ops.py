@@ -659,15 +659,35 @@ def gemm_tn_ring(v):
     return _lib.load().ldm_gemm_tn_ring(v)
 
 
+def tn_splits_one_round(tiles, m, slots=512, min_rows=256):
+    """Splits of the pixel reduction of the fp32 TN kernel such that tiles x splits fills ONE round of its workgroup slots (two per
+    CU) as fully as possible: the splits need not divide m (rows per split = m / splits rounded up to 32, the last one shorter).
+    Powers of two left 9 x 64 = 576 workgroups on 512 slots -- two rounds, the second one an eighth full -- for EVERY dense 3x3 conv
+    (9 (C / 128)^2 tiles)."""
+    s = max(1, min(slots // max(tiles, 1), m // min_rows))
+
+    def fits(v):
+        return (v - 1) * (((m + v - 1) // v + 31) // 32 * 32) < m
+
+    # multiples of 8 keep the kernel's XCD-aware order (the tiles of one split on one XCD: they share its rows of A and B in L2)
+    if s >= 8:
+        v = s - s % 8
+        while v >= 8 and not fits(v):
+            v -= 8
+        if v >= 8 and v * 20 >= s * 17:                        # ... unless that leaves more than 15 % of the slots empty
+            return v
+    while s > 1 and not fits(s):
+        s -= 1
+    return s
+
+
 def conv3x3_wgrad(dy, x, B, H, W, cin, cout, want_colsum=True):
     """(dW [cout, 9 * cin] fp32 with columns (tap, ci), column sums of dy [cout] or None) of a dense 3x3 conv (zero pad 1) from the
     gradient rows dy [B*H*W, cout] and the input rows x [B*H*W, cin]: implicit im2col inside the weight-gradient GEMM."""
     m = B * H * W
-    npad, kpad = (cout + 127) // 128 * 128, (9 * cin + 127) // 128 * 128
-    tiles = (npad // 128) * (kpad // 128)
-    s = 1
-    while tiles * s < 512 and m % (2 * s) == 0 and (m // (2 * s)) % 32 == 0 and m // (2 * s) >= 256 and s < 512:
-        s *= 2
+    npad, kpad = _lib.load().ldm_conv3x3_wgrad_npad(cout), (9 * cin + 127) // 128 * 128
+    tiles = (npad // min(npad, 128)) * (kpad // 128)           # tile height 32 / 64 for cout <= 32 / 64, else 128
+    s = tn_splits_one_round(tiles, m)
     dev = dy.device
     parts = torch.empty(s, npad, kpad, device=dev, dtype=torch.float32)
     cs = torch.empty(s, npad, device=dev, dtype=torch.float32) if want_colsum else None

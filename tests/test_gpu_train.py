@@ -21,9 +21,10 @@ def formula(module, gain=1.0):
     return module.cuda()
 
 
-@pytest.mark.parametrize("M,N,K,S", [(64, 128, 128, 1), (4096, 256, 128, 4), (2048, 128, 384, 2), (96, 384, 256, 3)])
+@pytest.mark.parametrize("M,N,K,S", [(64, 128, 128, 1), (4096, 256, 128, 4), (2048, 128, 384, 2), (96, 384, 256, 3), (4096, 128, 128, 7), (6272, 128, 256, 22)])
 def test_gemm_tn_weight_gradient_kernel(gpu_device, M, N, K, S):
-    """dW = dY^T X straight from the row-major operands (no transposed copies): every split plane and their sum."""
+    """dW = dY^T X straight from the row-major operands (no transposed copies): every split plane and their sum.  Splits that do not
+    divide M: rows per split = M / S rounded up to 32, the last split shorter."""
     from ldm_image_generator_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     dy = torch.randn(M, N, generator=g).cuda()
@@ -32,7 +33,7 @@ def test_gemm_tn_weight_gradient_kernel(gpu_device, M, N, K, S):
     cs = torch.empty(S, N, device=gpu_device)
     ops.gemm_tn(dy, x, parts, M, N, K, S, colsum=cs)
     assert rel_l2(cs.sum(0).double().cpu(), dy.double().sum(0).cpu()) < 1e-5
-    ms = M // S
+    ms = ((M + S - 1) // S + 31) // 32 * 32
     for s_ in range(S):
         ref = dy[s_ * ms:(s_ + 1) * ms].double().t() @ x[s_ * ms:(s_ + 1) * ms].double()
         assert rel_l2(parts[s_].double().cpu(), ref.cpu()) < 1e-5, s_
