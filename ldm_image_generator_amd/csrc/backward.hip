@@ -1591,7 +1591,7 @@ extern "C" int ldm_transpose_colsum_f32(const float *x, float *out, float *csum,
 extern "C" int ldm_reduce_partials_f32(const float *parts, float *out, int S, long long n, void *stream)
 {
     LDM_REQUIRE(parts && out && S > 0 && n > 0, "ldm_reduce_partials_f32: bad arguments");
-    if (n % 4 == 0 && S >= 4 && ldm_aligned16(parts) && ldm_aligned16(out))
+    if (n % 4 == 0 && ldm_aligned16(parts) && ldm_aligned16(out))
         hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3(blocks_for(n / 4, 64)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)parts,
                            (f32x4 *)out, S, n / 4);
     else
@@ -1656,7 +1656,7 @@ extern "C" int ldm_stem_bwd_f32(const float *x, const float *dy, float *dw, int 
     const long long M = (long long)B * HW;
     const long long nw = (long long)C0 * Cin;
     // every block writes its partial sums to ITS plane of the scratch; the planes are added in block order (bit-reproducible)
-    if (C0 <= 256 && Cin <= 16) {
+    if (C0 <= kRowsNT && Cin <= 16) {           // (the Decoder's 512-wide input layer too: the generic kernel below took 1.4 ms for its 8 k rows)
         long long per = ((M + 255) / 256 + kRowsNT - 1) / kRowsNT * kRowsNT;     // rows per block: ~256 blocks, whole 1024-row chunks
         if (per > 0x40000000LL) per = 0x40000000LL;
         const int slab = (int)per;
@@ -1689,7 +1689,7 @@ extern "C" int ldm_head_bwd_f32(const float *x, const float *w, const float *dou
     const long long plane = (long long)C0 * Cin + Cin;                 // [weight sums | bias sums] per block, added in block order afterwards
     unsigned nb;
     float *parts;
-    if (C0 <= 256) {
+    if (C0 <= kRowsNT) {
         const long long ntiles = (M + 255) / 256;
         nb = (unsigned)(ntiles < 256 ? ntiles : 256);
         parts = (float *)ldm_scratch(st, (size_t)(nb + 1) * plane * sizeof(float));
