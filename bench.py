@@ -321,124 +321,137 @@ def main():
     # UNet(input_channels=3); its 36 SwinBlocks and ch_convs are the SAME modules as the headline net (only stem / head differ).
     cfg2 = None
     if not args.no_cfg2_leg and args.mode == "eval":
-        net2 = UNet(input_channels=3, stages=[0, 0, 0, 0])                # cheap shell: stem, head and empty stages ...
-        for i in range(len(net.encoder_stages)):                          # ... filled with the headline net's stages
-            net2.encoder_stages[i] = net.encoder_stages[i]
-            net2.decoder_stages[i] = net.decoder_stages[i]
-        ends = {k: v for k, v in net2.state_dict().items() if k.startswith(("encoder_first", "decoder_last"))}
-        net2.load_state_dict(synth.fill_state_dict(ends), strict=False)
-        net2 = net2.to(dev).eval()
-        d2 = DDPM(model=net2)
-        b2 = 64
-        xp = torch.randn(b2, 3, 64, 64, generator=torch.Generator().manual_seed(0)).to(dev)
-        d2.sample((b2, 3, 64, 64), seed=0, num_steps=T, x_init=xp, progress=False)
-        fence()
-        ops.prof_enable(rank == 0)
-        t0 = time.perf_counter()
-        for i in range(2):
-            o2 = d2.sample((b2, 3, 64, 64), seed=100 + i, num_steps=T, x_init=xp, progress=False)
-        fence()
-        dtc = max_over_ranks(time.perf_counter() - t0)
-        l2c, msc, flc = ops.prof_read() if rank == 0 else (0, 0.0, 0.0)
-        ops.prof_enable(False)
-        famc = flc / (msc * 1e-3) / 1e12 if msc > 0 else None
-        cfg2 = {"value": b2 * world * 2 / dtc, "unit": "images/s", "denoise_steps_per_sec": 2 * T / dtc, "steps": 2, "ms_per_step": dtc / 2 * 1e3,
-                "config": {"workload": "sample_ddpm 64x64 pixel space, %d DDIM steps, batch %d per GPU, UNet(input_channels=3) only, eval-mode" % (T, b2)},
-                "gemm_tflops": famc, "outputs_finite": bool(torch.isfinite(o2).all().item()),
-                "roofline": None if famc is None else {"bound": "mfma", "achieved": famc, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                       "frac": famc / FP32_MFMA_PEAK_TFLOPS, "kernel": "ldm_gemm_f32 family, hipEvents per launch"},
-                "algorithmic_tflops": b2 * 2 * T * 54.98e9 / dtc / 1e12}
-        del net2, d2, o2, xp
-        torch.cuda.empty_cache()
+        try:
+            net2 = UNet(input_channels=3, stages=[0, 0, 0, 0])                # cheap shell: stem, head and empty stages ...
+            for i in range(len(net.encoder_stages)):                          # ... filled with the headline net's stages
+                net2.encoder_stages[i] = net.encoder_stages[i]
+                net2.decoder_stages[i] = net.decoder_stages[i]
+            ends = {k: v for k, v in net2.state_dict().items() if k.startswith(("encoder_first", "decoder_last"))}
+            net2.load_state_dict(synth.fill_state_dict(ends), strict=False)
+            net2 = net2.to(dev).eval()
+            d2 = DDPM(model=net2)
+            b2 = 64
+            xp = torch.randn(b2, 3, 64, 64, generator=torch.Generator().manual_seed(0)).to(dev)
+            d2.sample((b2, 3, 64, 64), seed=0, num_steps=T, x_init=xp, progress=False)
+            fence()
+            ops.prof_enable(rank == 0)
+            t0 = time.perf_counter()
+            for i in range(2):
+                o2 = d2.sample((b2, 3, 64, 64), seed=100 + i, num_steps=T, x_init=xp, progress=False)
+            fence()
+            dtc = max_over_ranks(time.perf_counter() - t0)
+            l2c, msc, flc = ops.prof_read() if rank == 0 else (0, 0.0, 0.0)
+            ops.prof_enable(False)
+            famc = flc / (msc * 1e-3) / 1e12 if msc > 0 else None
+            cfg2 = {"value": b2 * world * 2 / dtc, "unit": "images/s", "denoise_steps_per_sec": 2 * T / dtc, "steps": 2, "ms_per_step": dtc / 2 * 1e3,
+                    "config": {"workload": "sample_ddpm 64x64 pixel space, %d DDIM steps, batch %d per GPU, UNet(input_channels=3) only, eval-mode" % (T, b2)},
+                    "gemm_tflops": famc, "outputs_finite": bool(torch.isfinite(o2).all().item()),
+                    "roofline": None if famc is None else {"bound": "mfma", "achieved": famc, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                           "frac": famc / FP32_MFMA_PEAK_TFLOPS, "kernel": "ldm_gemm_f32 family, hipEvents per launch"},
+                    "algorithmic_tflops": b2 * 2 * T * 54.98e9 / dtc / 1e12}
+            del net2, d2, o2, xp
+            torch.cuda.empty_cache()
+        except Exception as exc:           # a secondary leg never takes the headline line down with it
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            cfg2 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            ops.prof_enable(False)
 
     # BASELINE.json configs[4]: one optimisation step of train_ldm.py:76-86 at the per-GPU shape of "global batch 1024 over
     # 8 GPUs, 512x512 -> latents [128, 8, 64, 64]": q-sample, UNet forward with the tape, L1 loss, hand-written backward,
     # (N > 1) the gradient all-reduce, AdamW.  Random-init formula weights, train mode (stochastic depth live), synthetic latents.
     train_step = None
     if not args.no_train_step_leg:
-        from ldm_image_generator_amd import train as ltrain
-        torch.cuda.empty_cache()
-        net.train(True)
-        # train_ldm.py:67 constructs torch.optim.AdamW; its fused=True flavour (one kernel per parameter chunk, same update rule)
-        # keeps the host out of the way: the foreach default costs 10-28 ms of host-bound time per step on 1376 tensors
-        opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4, fused=True)
-        # AdamW creates a parameter's state (step, exp_avg, exp_avg_sq: three zero-fills) the first time that parameter has a gradient;
-        # with 2-of-4 experts drawn per block and step, "first times" keep happening for dozens of steps (833 tiny fills per step in
-        # round 2's profile).  A run of any length has all of it allocated after its first epoch: allocate it before the timed steps.
-        for group in opt.param_groups:
-            for p_ in group["params"]:
-                st_ = opt.state[p_]
-                if len(st_) == 0:
-                    st_["step"] = torch.zeros((), dtype=torch.float32, device=p_.device)
-                    st_["exp_avg"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
-                    st_["exp_avg_sq"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
-        xb = torch.randn(args.train_batch, 8, args.train_latent, args.train_latent,
-                         generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
-        train_step = {"unit": "samples/s", "config": {"workload": "train_ldm step, latents [%d, 8, %d, %d] per GPU, UNet(385.7M) train mode, "
-                                                                  "L1 loss, torch.optim.AdamW(fused=True)" % (args.train_batch, args.train_latent, args.train_latent),
-                                                      "global_batch": args.train_batch * world, "steps": args.train_steps, "warmup": args.train_warmup}}
-        for prec in getattr(ltrain, "PRECISIONS", ("f32",)):
-            ltrain.set_precision(net, prec) if hasattr(ltrain, "set_precision") else None
-            torch.cuda.reset_peak_memory_stats()
-            for wi in range(args.train_warmup):                                   # warm-up: allocator, RCCL buffers, weight caches, and the
-                ldist.train_step(ddpm, opt, xb, 10000 + wi, world)                # optimizer state of the experts a step happens to pick
-            fence()
-            tstats = {}
-            t0 = time.perf_counter()
-            for i in range(args.train_steps):
-                loss = ldist.train_step(ddpm, opt, xb, 1 + i, world, stats=tstats)
-            fence()
-            dts = max_over_ranks(time.perf_counter() - t0)
-            leg = {"ms_per_step": dts / args.train_steps * 1e3, "value": args.train_batch * world * args.train_steps / dts,
-                   "loss": float(loss.detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
-            # per-kernel times come from the SAME steps run once more with a hipEvent pair around every MFMA launch (~1 000 events per
-            # step: they cost the bf16 step 1-3 ms, so they stay out of the timed steps, as in the autocast leg); every rank runs them
-            ops.prof_enable(rank == 0)
-            t0 = time.perf_counter()
-            for i in range(args.train_steps):
-                ldist.train_step(ddpm, opt, xb, 1 + i, world)
-            fence()
-            leg["ms_per_step_with_events"] = max_over_ranks(time.perf_counter() - t0) / args.train_steps * 1e3
-            if world > 1:                                  # bucketed all-reduce overlapped with the backward (dist.GradSync): what was NOT hidden
-                leg["allreduce_ms_exposed"] = tstats.get("allreduce_ms_exposed")
-                leg["allreduce_bytes_per_step"] = tstats.get("allreduce_bytes")
-            if prec == "bf16":
-                leg["gemm_ring"] = ops.gemm_ring(-1)      # 1 = 256x256 ring kernel for the large plain NT GEMMs (bit-identical to 0)
-            if rank == 0:
-                per, tot_ms, tot_fl = {}, 0.0, 0.0
-                tot_by = 0.0
-                for cls, name in PROF_CLASSES.items():
-                    n, ms, fl = ops.prof_read_class(cls)
-                    if n:
-                        by = ops.prof_read_bytes(cls)
-                        per[name] = {"launches_per_step": n // args.train_steps, "ms_per_step": ms / args.train_steps,
-                                     "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
-                                     "algorithmic_gb_per_s": by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None}
-                        tot_ms += ms
-                        tot_fl += fl
-                        tot_by += by
-                ops.prof_read()
-                peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else FP32_MFMA_PEAK_TFLOPS
-                ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-                gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-                leg["executed_gflop_per_step"] = tot_fl / 1e9 / args.train_steps
-                leg["mfma_kernel_ms_per_step"] = tot_ms / args.train_steps
-                mfma_view = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
-                hbm_view = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "note": "algorithmic operand bytes of the MFMA kernels (every operand once) / their kernel time"}
-                # fp32 operands: the exact-fp32 MFMA paces the step; bf16 operands: the same GEMMs are 16x cheaper and the step
-                # is paced by operand traffic (ridge 2500 / 6.3 = 400 FLOP/B vs 96-384 FLOP/B of these layers)
-                leg["roofline"] = dict(hbm_view if prec == "bf16" else mfma_view)
-                leg["roofline"].update({"kernel": "all MFMA kernels of the step (NT, TN weight-gradient, grouped conv), hipEvents per launch",
-                                        "other_view": mfma_view if prec == "bf16" else hbm_view, "per_kernel": per})
+        try:
+            from ldm_image_generator_amd import train as ltrain
+            torch.cuda.empty_cache()
+            net.train(True)
+            # train_ldm.py:67 constructs torch.optim.AdamW; its fused=True flavour (one kernel per parameter chunk, same update rule)
+            # keeps the host out of the way: the foreach default costs 10-28 ms of host-bound time per step on 1376 tensors
+            opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4, fused=True)
+            # AdamW creates a parameter's state (step, exp_avg, exp_avg_sq: three zero-fills) the first time that parameter has a gradient;
+            # with 2-of-4 experts drawn per block and step, "first times" keep happening for dozens of steps (833 tiny fills per step in
+            # round 2's profile).  A run of any length has all of it allocated after its first epoch: allocate it before the timed steps.
+            for group in opt.param_groups:
+                for p_ in group["params"]:
+                    st_ = opt.state[p_]
+                    if len(st_) == 0:
+                        st_["step"] = torch.zeros((), dtype=torch.float32, device=p_.device)
+                        st_["exp_avg"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
+                        st_["exp_avg_sq"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
+            xb = torch.randn(args.train_batch, 8, args.train_latent, args.train_latent,
+                             generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+            train_step = {"unit": "samples/s", "config": {"workload": "train_ldm step, latents [%d, 8, %d, %d] per GPU, UNet(385.7M) train mode, "
+                                                                      "L1 loss, torch.optim.AdamW(fused=True)" % (args.train_batch, args.train_latent, args.train_latent),
+                                                          "global_batch": args.train_batch * world, "steps": args.train_steps, "warmup": args.train_warmup}}
+            for prec in getattr(ltrain, "PRECISIONS", ("f32",)):
+                ltrain.set_precision(net, prec) if hasattr(ltrain, "set_precision") else None
+                torch.cuda.reset_peak_memory_stats()
+                for wi in range(args.train_warmup):                                   # warm-up: allocator, RCCL buffers, weight caches, and the
+                    ldist.train_step(ddpm, opt, xb, 10000 + wi, world)                # optimizer state of the experts a step happens to pick
+                fence()
+                tstats = {}
+                t0 = time.perf_counter()
+                for i in range(args.train_steps):
+                    loss = ldist.train_step(ddpm, opt, xb, 1 + i, world, stats=tstats)
+                fence()
+                dts = max_over_ranks(time.perf_counter() - t0)
+                leg = {"ms_per_step": dts / args.train_steps * 1e3, "value": args.train_batch * world * args.train_steps / dts,
+                       "loss": float(loss.detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+                # per-kernel times come from the SAME steps run once more with a hipEvent pair around every MFMA launch (~1 000 events per
+                # step: they cost the bf16 step 1-3 ms, so they stay out of the timed steps, as in the autocast leg); every rank runs them
+                ops.prof_enable(rank == 0)
+                t0 = time.perf_counter()
+                for i in range(args.train_steps):
+                    ldist.train_step(ddpm, opt, xb, 1 + i, world)
+                fence()
+                leg["ms_per_step_with_events"] = max_over_ranks(time.perf_counter() - t0) / args.train_steps * 1e3
+                if world > 1:                                  # bucketed all-reduce overlapped with the backward (dist.GradSync): what was NOT hidden
+                    leg["allreduce_ms_exposed"] = tstats.get("allreduce_ms_exposed")
+                    leg["allreduce_bytes_per_step"] = tstats.get("allreduce_bytes")
+                if prec == "bf16":
+                    leg["gemm_ring"] = ops.gemm_ring(-1)      # 1 = 256x256 ring kernel for the large plain NT GEMMs (bit-identical to 0)
+                if rank == 0:
+                    per, tot_ms, tot_fl = {}, 0.0, 0.0
+                    tot_by = 0.0
+                    for cls, name in PROF_CLASSES.items():
+                        n, ms, fl = ops.prof_read_class(cls)
+                        if n:
+                            by = ops.prof_read_bytes(cls)
+                            per[name] = {"launches_per_step": n // args.train_steps, "ms_per_step": ms / args.train_steps,
+                                         "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                                         "algorithmic_gb_per_s": by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None}
+                            tot_ms += ms
+                            tot_fl += fl
+                            tot_by += by
+                    ops.prof_read()
+                    peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else FP32_MFMA_PEAK_TFLOPS
+                    ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+                    gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+                    leg["executed_gflop_per_step"] = tot_fl / 1e9 / args.train_steps
+                    leg["mfma_kernel_ms_per_step"] = tot_ms / args.train_steps
+                    mfma_view = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+                    hbm_view = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "note": "algorithmic operand bytes of the MFMA kernels (every operand once) / their kernel time"}
+                    # fp32 operands: the exact-fp32 MFMA paces the step; bf16 operands: the same GEMMs are 16x cheaper and the step
+                    # is paced by operand traffic (ridge 2500 / 6.3 = 400 FLOP/B vs 96-384 FLOP/B of these layers)
+                    leg["roofline"] = dict(hbm_view if prec == "bf16" else mfma_view)
+                    leg["roofline"].update({"kernel": "all MFMA kernels of the step (NT, TN weight-gradient, grouped conv), hipEvents per launch",
+                                            "other_view": mfma_view if prec == "bf16" else hbm_view, "per_kernel": per})
+                ops.prof_enable(False)
+                train_step[prec] = leg
+            if hasattr(ltrain, "set_precision"):
+                ltrain.set_precision(net, "f32")
+            if "bf16" in train_step and "f32" in train_step:
+                train_step["bf16_over_f32"] = train_step["bf16"]["value"] / train_step["f32"]["value"]
+            del opt, xb
+            net.train(args.mode == "train")
+        except Exception as exc:           # a secondary leg never takes the headline line down with it
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            train_step = {"error": "%s: %s" % (type(exc).__name__, exc)}
             ops.prof_enable(False)
-            train_step[prec] = leg
-        if hasattr(ltrain, "set_precision"):
-            ltrain.set_precision(net, "f32")
-        if "bf16" in train_step and "f32" in train_step:
-            train_step["bf16_over_f32"] = train_step["bf16"]["value"] / train_step["f32"]["value"]
-        del opt, xb
-        net.train(args.mode == "train")
+            net.train(args.mode == "train")
 
     # one iteration of train_vae.py's loop (train_vae.py:104-127) -- VAE objective (L1 reconstruction x 10 + VQ loss +
     # 0.1 x generator hinge through the Discriminator) backward + optimizer, then the Discriminator's own hinge step -- on synthetic
@@ -446,70 +459,76 @@ def main():
     # for transformers' Adafactor (not on the hot path; `transformers` optimizers are out of scope).
     vae_step = None
     if not args.no_vae_train_leg:
-        from ldm_image_generator_amd.vae import VAE, Discriminator, Encoder, VectorQuantizer
-        torch.cuda.empty_cache()
-        enc_v, dec_v, disc_v = Encoder(), Decoder(), Discriminator()
-        for m_ in (enc_v, dec_v, disc_v):
-            m_.load_state_dict(synth.fill_state_dict(m_.state_dict()))
-        torch.manual_seed(1234)
-        vq_v = VectorQuantizer()
-        vae_v = VAE(enc_v, dec_v, vq_v).to(dev)
-        disc_v = disc_v.to(dev)
-        opt_v = torch.optim.AdamW(vae_v.parameters(), lr=1e-4, fused=True)
-        opt_dv = torch.optim.AdamW(disc_v.parameters(), lr=1e-4, fused=True)
-        vb, vs = args.vae_batch, args.vae_size
-        img_v = (torch.rand(vb, 3, vs, vs, generator=torch.Generator().manual_seed(7 + rank)) * 2 - 1).to(dev)
+        try:
+            from ldm_image_generator_amd.vae import VAE, Discriminator, Encoder, VectorQuantizer
+            torch.cuda.empty_cache()
+            enc_v, dec_v, disc_v = Encoder(), Decoder(), Discriminator()
+            for m_ in (enc_v, dec_v, disc_v):
+                m_.load_state_dict(synth.fill_state_dict(m_.state_dict()))
+            torch.manual_seed(1234)
+            vq_v = VectorQuantizer()
+            vae_v = VAE(enc_v, dec_v, vq_v).to(dev)
+            disc_v = disc_v.to(dev)
+            opt_v = torch.optim.AdamW(vae_v.parameters(), lr=1e-4, fused=True)
+            opt_dv = torch.optim.AdamW(disc_v.parameters(), lr=1e-4, fused=True)
+            vb, vs = args.vae_batch, args.vae_size
+            img_v = (torch.rand(vb, 3, vs, vs, generator=torch.Generator().manual_seed(7 + rank)) * 2 - 1).to(dev)
 
-        def vae_iter():
-            opt_v.zero_grad()
-            recon, reg, y = vae_v.calclate_loss(img_v)
-            adv = torch.relu(-disc_v.calclate_logit(y)).mean()
-            (recon * 10.0 + reg * 1.0 + adv * 0.1).backward()
-            opt_v.step()
-            opt_dv.zero_grad()
-            y = y.detach()
-            d_loss = torch.relu(1 + disc_v.calclate_logit(y)).mean() + torch.relu(1 - disc_v.calclate_logit(img_v)).mean()
-            d_loss.backward()
-            opt_dv.step()
-            return recon, reg, adv, d_loss
+            def vae_iter():
+                opt_v.zero_grad()
+                recon, reg, y = vae_v.calclate_loss(img_v)
+                adv = torch.relu(-disc_v.calclate_logit(y)).mean()
+                (recon * 10.0 + reg * 1.0 + adv * 0.1).backward()
+                opt_v.step()
+                opt_dv.zero_grad()
+                y = y.detach()
+                d_loss = torch.relu(1 + disc_v.calclate_logit(y)).mean() + torch.relu(1 - disc_v.calclate_logit(img_v)).mean()
+                d_loss.backward()
+                opt_dv.step()
+                return recon, reg, adv, d_loss
 
-        for _ in range(2):
-            vae_iter()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.vae_steps):
-            losses = vae_iter()
-        fence()
-        dtv = max_over_ranks(time.perf_counter() - t0)
-        ops.prof_enable(rank == 0)                       # per-kernel times: the same iterations once more, with hipEvents (see train_step)
-        for _ in range(args.vae_steps):
-            vae_iter()
-        fence()
-        vae_step = {"ms_per_step": dtv / args.vae_steps * 1e3, "value": vb * world * args.vae_steps / dtv, "unit": "images/s", "dtype": "f32",
-                    "config": {"workload": "train_vae.py iteration: VAE loss + generator hinge backward + AdamW, then Discriminator hinge step + AdamW; "
-                                           "images [%d, 3, %d, %d] per GPU, Encoder / Decoder / VectorQuantizer(8192 x 8) / Discriminator at default widths" % (vb, vs, vs),
-                               "steps": args.vae_steps, "warmup": 2},
-                    "losses": {"recon": float(losses[0]), "reg": float(losses[1]), "adv": float(losses[2]), "disc": float(losses[3])},
-                    "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
-        if rank == 0:
-            per, tot_ms, tot_fl, tot_by = {}, 0.0, 0.0, 0.0
-            for cls, name in PROF_CLASSES.items():
-                n, ms, fl = ops.prof_read_class(cls)
-                if n:
-                    by = ops.prof_read_bytes(cls)
-                    per[name] = {"launches_per_step": n // args.vae_steps, "ms_per_step": ms / args.vae_steps, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None}
-                    tot_ms, tot_fl, tot_by = tot_ms + ms, tot_fl + fl, tot_by + by
-            ops.prof_read()
-            if tot_ms > 0:
-                ach = tot_fl / (tot_ms * 1e-3) / 1e12
-                vae_step["executed_gflop_per_step"] = tot_fl / 1e9 / args.vae_steps
-                vae_step["mfma_kernel_ms_per_step"] = tot_ms / args.vae_steps
-                vae_step["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                                        "kernel": "all MFMA kernels of the iteration (implicit 3x3 NT GEMMs, TN / NT weight-gradient GEMMs), hipEvents per launch",
-                                        "per_kernel": per}
-        ops.prof_enable(False)
-        del vae_v, disc_v, opt_v, opt_dv, img_v
-        torch.cuda.empty_cache()
+            for _ in range(2):
+                vae_iter()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.vae_steps):
+                losses = vae_iter()
+            fence()
+            dtv = max_over_ranks(time.perf_counter() - t0)
+            ops.prof_enable(rank == 0)                       # per-kernel times: the same iterations once more, with hipEvents (see train_step)
+            for _ in range(args.vae_steps):
+                vae_iter()
+            fence()
+            vae_step = {"ms_per_step": dtv / args.vae_steps * 1e3, "value": vb * world * args.vae_steps / dtv, "unit": "images/s", "dtype": "f32",
+                        "config": {"workload": "train_vae.py iteration: VAE loss + generator hinge backward + AdamW, then Discriminator hinge step + AdamW; "
+                                               "images [%d, 3, %d, %d] per GPU, Encoder / Decoder / VectorQuantizer(8192 x 8) / Discriminator at default widths" % (vb, vs, vs),
+                                   "steps": args.vae_steps, "warmup": 2},
+                        "losses": {"recon": float(losses[0]), "reg": float(losses[1]), "adv": float(losses[2]), "disc": float(losses[3])},
+                        "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            if rank == 0:
+                per, tot_ms, tot_fl, tot_by = {}, 0.0, 0.0, 0.0
+                for cls, name in PROF_CLASSES.items():
+                    n, ms, fl = ops.prof_read_class(cls)
+                    if n:
+                        by = ops.prof_read_bytes(cls)
+                        per[name] = {"launches_per_step": n // args.vae_steps, "ms_per_step": ms / args.vae_steps, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None}
+                        tot_ms, tot_fl, tot_by = tot_ms + ms, tot_fl + fl, tot_by + by
+                ops.prof_read()
+                if tot_ms > 0:
+                    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+                    vae_step["executed_gflop_per_step"] = tot_fl / 1e9 / args.vae_steps
+                    vae_step["mfma_kernel_ms_per_step"] = tot_ms / args.vae_steps
+                    vae_step["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                                            "kernel": "all MFMA kernels of the iteration (implicit 3x3 NT GEMMs, TN / NT weight-gradient GEMMs), hipEvents per launch",
+                                            "per_kernel": per}
+            ops.prof_enable(False)
+            del vae_v, disc_v, opt_v, opt_dv, img_v
+            torch.cuda.empty_cache()
+        except Exception as exc:           # a secondary leg never takes the headline line down with it
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            vae_step = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            ops.prof_enable(False)
 
     if rank == 0:
         images = gb * args.steps
