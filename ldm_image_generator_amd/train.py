@@ -781,7 +781,7 @@ class UNetFunction(torch.autograd.Function):
             rows = run_stage(l.stage, rows, (b, h, w))
         out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
         wl = net.decoder_last.weight.detach().reshape(c0, cin)
-        ops.head_nchw(rows, wl, net.decoder_last.bias.detach(), out, b, c0, h * w, cin)
+        ops.head_nchw(rows, wl, net._head_bias(), out, b, c0, h * w, cin)
         fctx.net, fctx.tape, fctx.tctx, fctx.x, fctx.last_rows, fctx.params, fctx.bf16 = net, tape, ctx, x, rows, params, bf16
         return out
 
@@ -798,7 +798,8 @@ class UNetFunction(torch.autograd.Function):
         dbl = torch.empty(cin, device=dev, dtype=torch.float32)
         ops.head_bwd(rows, net.decoder_last.weight.detach().reshape(c0, cin), dout.contiguous().float(), drows, dwl, dbl, b, c0, h * w, cin)
         grads.add(net.decoder_last.weight, dwl)
-        grads.add(net.decoder_last.bias, dbl)
+        ss = net.stem_size * net.stem_size                 # stem_size > 1: the head bias was replicated over the s x s patch positions
+        grads.add(net.decoder_last.bias, dbl if ss == 1 else dbl.reshape(cin // ss, ss).sum(1))
         dskip = {}
         drows16 = None                                       # bf16 shadow of drows (bf16 mode): produced by the block that wrote drows
         # data-parallel step: hand each finished level's gradients to the bucketed all-reduce while the next level computes

@@ -19,6 +19,7 @@ import random
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops, sinusoidal, weights
 from .attention import CrossAttention, WindowAttention
@@ -196,8 +197,12 @@ class UNetBlock(nn.Module):
 class UNet(nn.Module):
     def __init__(self, input_channels=8, stages=[3, 3, 9, 3], channels=[128, 256, 512, 1024], stem_size=1):
         super().__init__()
-        if stem_size != 1:
-            raise NotImplementedError("only stem_size == 1 (the reference default) is implemented in HIP")
+        if not (isinstance(stem_size, int) and stem_size >= 1):
+            raise ValueError("stem_size must be a positive integer")
+        # stem_size = s > 1 (unet.py:77-78: a stride-s patchify conv in, its ConvTranspose2d out): forward() re-tiles the image with
+        # pixel_unshuffle / pixel_shuffle and every path below sees a 1x1 stem / head over input_channels * s * s channels -- the two
+        # weights [C0, Cin, s, s] ARE the [C0, Cin s^2] matrices of that 1x1 problem, in place
+        self.stem_size = stem_size
         self.encoder_first = nn.Conv2d(input_channels, channels[0], stem_size, stem_size, 0)
         self.decoder_last = nn.ConvTranspose2d(channels[0], input_channels, stem_size, stem_size, 0)
         self.encoder_stages = nn.ModuleList([])
@@ -228,6 +233,11 @@ class UNet(nn.Module):
         self._autocast_now = False         # set by DDPM.sample for the duration of an autocast loop
         self._grad_sync = None             # dist.GradSync of the current data-parallel step (dist.train_step), else None
         self._plan16 = None
+
+    def _head_bias(self):
+        """decoder_last.bias as the 1x1 head over Cin * s^2 channels needs it: every channel's value once per position of its s x s patch."""
+        bias = self.decoder_last.bias.detach()
+        return bias if self.stem_size == 1 else bias.repeat_interleave(self.stem_size * self.stem_size)
 
     def _level_blocks(self, i):
         n = len(self.encoder_stages)
@@ -280,7 +290,8 @@ class UNet(nn.Module):
         if self._plan is not None:
             order, captured = self._plan[3], self._plan[4]
             key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured),
-                   tuple(blk.conv.weight._version for blk in order), weights.GENERATION[0])
+                   tuple(blk.conv.weight._version for blk in order), weights.GENERATION[0],
+                   self.decoder_last.bias._version if self.stem_size > 1 else 0)          # (the replicated head bias is a copy)
             if self._plan[0] == key:
                 return self._plan[1]
         order = [blk for l in self.encoder_stages for blk in l.stage.blocks] + [blk for l in self.decoder_stages for blk in l.stage.blocks]
@@ -313,7 +324,7 @@ class UNet(nn.Module):
                 bd.out_w, bd.out_b = ptr(att.out_proj.weight), ptr(att.out_proj.bias)
         plan = UNetPlanDesc()
         n = len(self.encoder_stages)
-        plan.levels, plan.input_channels, plan.window, plan.nblocks = n, self.input_channels, 6, len(order)
+        plan.levels, plan.input_channels, plan.window, plan.nblocks = n, self.input_channels * self.stem_size ** 2, 6, len(order)
         plan.eps = order[0].norm.eps
         for i in range(n):
             plan.channels[i] = self.channels[i]
@@ -327,11 +338,11 @@ class UNet(nn.Module):
                 plan.down_w[i], plan.down_b[i] = ptr(down.weight), ptr(down.bias)
                 plan.up_w[i], plan.up_b[i] = ptr(up.weight), ptr(up.bias)
         plan.stem_w, plan.stem_b = ptr(self.encoder_first.weight), ptr(self.encoder_first.bias)
-        plan.head_w, plan.head_b = ptr(self.decoder_last.weight), ptr(self.decoder_last.bias)
+        plan.head_w, plan.head_b = ptr(self.decoder_last.weight), ptr(self.decoder_last.bias if self.stem_size == 1 else self._head_bias())
         plan.blocks = ctypes.cast(blocks, ctypes.POINTER(UNetBlockDesc))
         keep.append(blocks)
         key = (str(dev), _PARAM_GENERATION[0], tuple(t.data_ptr() for t in captured), tuple(blk.conv.weight._version for blk in order),
-               weights.GENERATION[0])
+               weights.GENERATION[0], self.decoder_last.bias._version if self.stem_size > 1 else 0)
         self._plan = (key, plan, keep, order, captured)
         return plan
 
@@ -463,6 +474,15 @@ class UNet(nn.Module):
         return out
 
     def forward(self, x, time, condition=None):
+        s = self.stem_size
+        if s == 1:
+            return self._forward_1x1(x, time)
+        if x.shape[-1] % s or x.shape[-2] % s:
+            raise ValueError("UNet: input %dx%d is not divisible by stem_size %d" % (x.shape[-2], x.shape[-1], s))
+        # channel ci * s^2 + dy * s + dx of the re-tiled image is pixel (dy, dx) of the patch: the order of encoder_first.weight[:, ci, dy, dx]
+        return F.pixel_shuffle(self._forward_1x1(F.pixel_unshuffle(x, s), time), s)
+
+    def _forward_1x1(self, x, time):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training step: same kernels + saved activations, hand-written backward (train.py).  Like the reference's autograd this
             # keeps every block's activations alive (~21 C floats per pixel and block: 63 GB fp32 / 43 GB bf16 at the cfg-5 shape)
@@ -519,5 +539,5 @@ class UNet(nn.Module):
             rows = l.stage.forward_rows(rows, (b, h, w), ctx, plan)
         out = torch.empty(b, cin, h, w, device=dev, dtype=torch.float32)
         wl = self.decoder_last.weight.detach().reshape(c0, cin)         # ConvTranspose2d weight [C0, Cin, 1, 1]
-        ops.head_nchw(rows, wl, self.decoder_last.bias.detach(), out, b, c0, h * w, cin)
+        ops.head_nchw(rows, wl, self._head_bias(), out, b, c0, h * w, cin)
         return out

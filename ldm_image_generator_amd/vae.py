@@ -351,8 +351,9 @@ class Discriminator(nn.Module):
 
     def __init__(self, input_channels=3, channels=[32, 48, 48, 96], stages=[2, 2, 2, 2], stem_size=1):
         super().__init__()
-        if stem_size != 1:
-            raise NotImplementedError("Discriminator: stem_size != 1 is not on the HIP path")
+        if not (isinstance(stem_size, int) and stem_size >= 1):
+            raise ValueError("stem_size must be a positive integer")
+        self.stem_size = stem_size          # > 1: a stride-s patchify conv = 1x1 over the pixel_unshuffle'd image (see unet.UNet)
         self.input_layer = nn.Conv2d(input_channels, channels[0], stem_size, stem_size, 0)
         self.stages = nn.ModuleList([ResStack(c, l) for c, l in zip(channels, stages)])
         self.early_exits = nn.ModuleList([])
@@ -366,6 +367,10 @@ class Discriminator(nn.Module):
 
     def _run(self, fake_x, real_x):
         from .vae_train import DiscriminatorFunction
+        if self.stem_size > 1:
+            import torch.nn.functional as F
+            fake_x = F.pixel_unshuffle(fake_x, self.stem_size)
+            real_x = None if real_x is None else F.pixel_unshuffle(real_x, self.stem_size)
         return DiscriminatorFunction.apply(self, fake_x, real_x, *[p for p in self.parameters() if p.requires_grad])
 
     def calclate_logit_and_feature_matching(self, fake_x, real_x):

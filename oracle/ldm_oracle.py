@@ -241,7 +241,9 @@ def unet_forward(sd, x, t, stages=(3, 3, 9, 3), channels=(128, 256, 512, 1024), 
     ever calls .eval() -- sampling runs with stochastic depth live."""
     p = prefix
     ns = len(stages)
-    x = _pointwise(x, sd[p + "encoder_first.weight"], sd[p + "encoder_first.bias"])
+    w0 = sd[p + "encoder_first.weight"]                   # Conv2d(Cin, C0, stem_size, stem_size, 0)  (unet.py:77)
+    stem = w0.shape[-1]
+    x = _pointwise(x, w0, sd[p + "encoder_first.bias"]) if stem == 1 else F.conv2d(x, w0, sd[p + "encoder_first.bias"], stride=stem)
     skips = []
     for i in range(ns):
         x = swin_stack(sd, "%sencoder_stages.%d.stage." % (p, i), x, t, stages[i], False, training, decisions)
@@ -262,6 +264,8 @@ def unet_forward(sd, x, t, stages=(3, 3, 9, 3), channels=(128, 256, 512, 1024), 
         x = swin_stack(sd, "%sdecoder_stages.%d.stage." % (p, j), x, t, stages[i], True, training, decisions)
     # decoder_last = ConvTranspose2d(C0, Cin, 1, 1): weight [C0, Cin, 1, 1]  (unet.py:78)
     w = sd[p + "decoder_last.weight"]
+    if stem > 1:                                           # ConvTranspose2d(C0, Cin, stem_size, stem_size, 0): weight [C0, Cin, s, s]
+        return F.conv_transpose2d(x, w, sd[p + "decoder_last.bias"], stride=stem)
     y = torch.einsum("co,nchw->nohw", w.reshape(w.shape[0], w.shape[1]), x)
     return y + sd[p + "decoder_last.bias"].reshape(1, -1, 1, 1)
 
@@ -393,7 +397,8 @@ def discriminator_features(sd, x, stages=(2, 2, 2, 2), prefix=""):
     """vae.py:149-171 (both ``calclate_logit*`` walk the same layers): the per-stage feature maps after each ResStack and the
     per-stage early-exit maps c(x) (1 channel); Conv2d(c, c', 2, 2) between stages."""
     p = prefix
-    y = _pointwise(x, sd[p + "input_layer.weight"], sd[p + "input_layer.bias"])
+    w_in = sd[p + "input_layer.weight"]                   # Conv2d(Cin, C0, stem_size, stem_size, 0)  (vae.py:137)
+    y = _pointwise(x, w_in, sd[p + "input_layer.bias"]) if w_in.shape[-1] == 1 else F.conv2d(x, w_in, sd[p + "input_layer.bias"], stride=w_in.shape[-1])
     feats, exits = [], []
     for s, nblk in enumerate(stages):
         for k in range(nblk):
@@ -475,12 +480,13 @@ def swin_block_shapes(out, p, c, attention, head_dim=32):
     _conv_keys(out, p + "encodings.proj2.", 2 * c, 4 * c)
 
 
-def unet_state_shapes(input_channels=8, stages=(3, 3, 9, 3), channels=(128, 256, 512, 1024), prefix=""):
+def unet_state_shapes(input_channels=8, stages=(3, 3, 9, 3), channels=(128, 256, 512, 1024), prefix="", stem_size=1):
     out = {}
     p = prefix
     ns = len(stages)
     _conv_keys(out, p + "encoder_first.", channels[0], input_channels)
-    out[p + "decoder_last.weight"] = (channels[0], input_channels, 1, 1)
+    out[p + "encoder_first.weight"] = (channels[0], input_channels, stem_size, stem_size)
+    out[p + "decoder_last.weight"] = (channels[0], input_channels, stem_size, stem_size)
     out[p + "decoder_last.bias"] = (input_channels,)
     for i in range(ns):
         for b in range(stages[i]):

@@ -475,7 +475,53 @@ def vq_cases():
     save("vq", **arrs)
 
 
+def stem_cases():
+    """stem_size = 2 (unet.py:75-78: patchify conv in, ConvTranspose2d out), pixel-space tiny net: eval forward, and one
+    calculate_loss backward in train mode (all gradient norms, the two stem / head weight gradients and the head bias gradient)."""
+    net = load_formula(ref_unet.UNet(input_channels=3, stages=[1, 2], channels=[32, 64], stem_size=2))
+    x = g("stem2.x", (3, 3, 32, 24))
+    t = torch.tensor([5, 5, 700])
+    arrs = dict(x=x, t=t)
+    net.eval()
+    random.seed(2)
+    with torch.no_grad():
+        arrs["y_eval"] = net(x, t)
+    net.train()
+    d = ref_ddpm.DDPM(model=net)
+    xl = g("stem2.loss.x", (4, 3, 16, 16))
+    torch.manual_seed(5)
+    random.seed(5)
+    st = torch.get_rng_state()
+    tl = torch.randint(low=1, high=1000, size=(4,))
+    el = torch.randn(4, 3, 16, 16)
+    torch.set_rng_state(st)
+    with Trace() as tr:
+        loss = d.calculate_loss(xl)
+    loss.backward()
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(-1.0 if p.grad is None else float(p.grad.double().norm()))
+    arrs.update(loss_x=xl, loss_t=tl, loss_e=el, loss=loss.detach(), trace=tr.encoded(), grad_names=np.asarray(names), grad_norms=np.asarray(norms),
+                grad_encoder_first_weight=net.encoder_first.weight.grad, grad_decoder_last_weight=net.decoder_last.weight.grad,
+                grad_decoder_last_bias=net.decoder_last.bias.grad)
+    # Discriminator(stem_size=2) (vae.py:135-137): logit + feature distance, gradient at the fake batch, every parameter-gradient norm
+    disc = load_formula(ref_vae.Discriminator(channels=[32, 64], stages=[1, 1], stem_size=2), salt=4)
+    fake = g("stem2.disc.fake", (2, 3, 32, 32)).clone().requires_grad_()
+    real = g("stem2.disc.real", (2, 3, 32, 32))
+    logit, feat = disc.calclate_logit_and_feature_matching(fake, real.clone())
+    (logit * 0.5 + feat).backward()
+    dn = [k for k, p_ in disc.named_parameters() if p_.grad is not None]
+    arrs.update(disc_fake=fake.detach(), disc_real=real, disc_logit=logit.detach(), disc_feat=feat.detach(), disc_dfake=fake.grad,
+                disc_names=np.asarray(dn), disc_gradnorms=np.asarray([float(dict(disc.named_parameters())[k].grad.double().norm()) for k in dn]),
+                disc_grad_input_layer_weight=disc.input_layer.weight.grad)
+    save("unet_stem2", **arrs)
+
+
 if __name__ == "__main__":
+    if "--stem-only" in sys.argv:
+        stem_cases()
+        sys.exit(0)
     if "--vq-only" in sys.argv:
         vq_cases()
         sys.exit(0)
@@ -498,6 +544,7 @@ if __name__ == "__main__":
     tiny, full = unet_cases()
     sample_cases(tiny, full)
     loss_cases(tiny)
+    stem_cases()
     loss_full_cases()
     vae_cases()
     encoder_cases()

@@ -101,6 +101,30 @@ def test_unet_pixel_space_3ch(gpu_device):
     assert rel_l2(net(T(g["x"]).cuda(), T(g["t"]).cuda()).cpu(), T(g["y_eval"])) < 2e-5
 
 
+def test_unet_stem_size_2(gpu_device):
+    """stem_size = 2 (unet.py:75-78; the reference's stride-2 Conv2d / ConvTranspose2d pair): native executor, Python path and the
+    opt-in bf16 forward all run it as a 1x1 stem / head over the pixel_unshuffle'd image."""
+    from ldm_image_generator_amd.unet import UNet
+    g = load_golden("unet_stem2")
+    net = formula(UNet(input_channels=3, stages=[1, 2], channels=[32, 64], stem_size=2)).eval()
+    assert net.encoder_first.weight.shape == (32, 3, 2, 2) and net.decoder_last.weight.shape == (32, 3, 2, 2)
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    with torch.no_grad():
+        random.seed(2)
+        y = net(x, t)
+        assert y.shape == x.shape and rel_l2(y.cpu(), T(g["y_eval"])) < 2e-5
+        net.native_forward = False
+        random.seed(2)
+        assert rel_l2(net(x, t).cpu(), T(g["y_eval"])) < 2e-5
+        net.native_forward = True
+        with torch.no_grad():
+            net.decoder_last.bias.add_(0.5)                      # the replicated head bias of the native plan follows the parameter
+        random.seed(2)
+        assert rel_l2((net(x, t) - 0.5).cpu(), T(g["y_eval"])) < 2e-5
+    with pytest.raises(ValueError):
+        net(x[:, :, :31], t)
+
+
 def test_unet_full_size(full_unet):
     g = load_golden("unet_full")
     x, t = T(g["x"]).cuda(), T(g["t"]).cuda()

@@ -156,6 +156,17 @@ def test_unet_tiny_pixel_space():
     assert rel_l2(y, T(g["y_eval"])) < TOL
 
 
+def test_unet_stem_size_2():
+    """stem_size = 2 (unet.py:75-78): stride-2 patchify conv in, ConvTranspose2d out."""
+    g = load_golden("unet_stem2")
+    cfg = dict(stages=(1, 2), channels=(32, 64))
+    sd = O.formula_state(O.unet_state_shapes(3, stem_size=2, **cfg))
+    assert sd["encoder_first.weight"].shape == (32, 3, 2, 2) and sd["decoder_last.weight"].shape == (32, 3, 2, 2)
+    random.seed(2)
+    y = O.unet_forward(sd, T(g["x"]), T(g["t"]), training=False, **cfg)
+    assert y.shape == tuple(g["y_eval"].shape) and rel_l2(y, T(g["y_eval"])) < TOL
+
+
 def test_unet_full_size():
     g = load_golden("unet_full")
     shapes = O.unet_state_shapes()
