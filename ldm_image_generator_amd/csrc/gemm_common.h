@@ -50,7 +50,10 @@ static __device__ __attribute__((aligned(64))) float ldm_zero_block[16];
 // while they stream through K together -> both operands are served by the XCD's L2 instead of the
 // fabric (measured with the n-fastest order: 13-19x the algorithmic fetch at C = 512 / 1024, W re-read
 // from beyond L2 for every M-tile).
-constexpr int kBandM = 8;
+#ifndef LDM_BAND_M
+#define LDM_BAND_M 8
+#endif
+constexpr int kBandM = LDM_BAND_M;      // (-DLDM_BAND_M=n: probe builds of tools/band_probe.py)
 __device__ __forceinline__ void tile_from_id(int rem, int ntm, int ntn, int &tile_m, int &tile_n)
 {
     const int band = rem / (kBandM * ntn);
