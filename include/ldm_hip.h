@@ -195,6 +195,10 @@ int ldm_qsample_f32(const float *x, const float *e, const float *sa, const float
  * prev [B,3,H/2,W/2] and out [B,3,H,W] are NCHW like the reference's result. */
 int ldm_rgb_head_f32(const float *x, const float *w, const float *bias, const float *prev, float *out,
                      int B, int H, int W, int C, void *stream);
+/* the same with OC output channels (DecoderStack(channels, num_layers, output_channels), vae.py:100-103; 1 <= OC <= 4): w [OC, C], bias [OC],
+ * prev / out [B, OC, ., .]; ldm_rgb_head_f32 is OC = 3 */
+int ldm_rgb_head_oc_f32(const float *x, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, int OC,
+                        void *stream);
 
 /* layout plumbing at the boundary */
 int ldm_nchw_to_nhwc_f32(const float *x, float *out, int B, int C, int HW, void *stream);
@@ -398,6 +402,8 @@ int ldm_space_to_depth2_f32(const float *fine, float *out, int B, int H, int W, 
  * or NULL) += adjoint of the bilinear x2; dw [3, C] and db [3] (zeroed by the caller) += the to_rgb weight / bias gradient */
 int ldm_rgb_head_bwd_f32(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *dprev, float *dw,
                          float *db, int B, int H, int W, int C, void *stream);
+int ldm_rgb_head_bwd_oc_f32(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *dprev, float *dw,
+                            float *db, int B, int H, int W, int C, int OC, void *stream);      /* OC output channels (1..4) */
 
 /* Grouped 3x3 conv of unet.py:30,44 (32 in / 32 out per group, zero pad 1) with bf16 operands, fp32 accumulate:
  * out[m, :] = conv(x)[m, :] (+ bias) (+ addend[m, :]);  x [B*H*W, C] bf16, w [C][9][32] bf16 (ldm_gemm_f32's packed grouped
@@ -454,6 +460,8 @@ int ldm_stem_nchw_bf16(const float *x, const float *w, const float *bias, void *
 int ldm_depth_to_space2_bf16(const void *in_bf16, void *out_bf16, int B, int H, int W, int C, void *stream);
 /* ldm_rgb_head_f32 on bf16 rows (vae.py:104,131): out / prev stay fp32 NCHW planes */
 int ldm_rgb_head_bf16(const void *x_bf16, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, void *stream);
+int ldm_rgb_head_oc_bf16(const void *x_bf16, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, int OC,
+                         void *stream);                                                        /* OC output channels (1..4) */
 /* out[(b, y, x), :] = coarse[(b, y/2, x/2), :] (+ skip[(b, y, x), :]) on fp32 rows; H, W are the COARSE sizes (unet.py:85,101 split
  * from its GEMM) */
 int ldm_up2_add_f32(const float *coarse, const float *skip, float *out, int B, int H, int W, int C, void *stream);

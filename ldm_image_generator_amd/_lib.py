@@ -120,6 +120,7 @@ SIGNATURES = {
     "ldm_ddim_update_f32": (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "ldm_qsample_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "ldm_rgb_head_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_rgb_head_oc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "ldm_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "ldm_to_uint8_hwc": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -176,6 +177,7 @@ SIGNATURES = {
     "ldm_im2col3x3_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_space_to_depth2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_rgb_head_bwd_f32": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_rgb_head_bwd_oc_f32": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_gconv_pack_bf16": (_I, [_P, _P, _P, _I, _P]),
     "ldm_replicate_f32": (_I, [_P, _P, _I, _I, _P]),
     "ldm_multi_cast_table_bytes": (ctypes.c_size_t, [_I]),
@@ -189,6 +191,7 @@ SIGNATURES = {
     "ldm_stem_nchw_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_depth_to_space2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_rgb_head_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ldm_rgb_head_oc_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_up2_add_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ldm_avgpool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ldm_unet_streams": (_I, [_I]),

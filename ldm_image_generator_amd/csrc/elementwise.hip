@@ -346,7 +346,9 @@ __global__ void qsample_kernel(const float *__restrict__ x, const float *__restr
     out[i] = __fadd_rn(__fmul_rn(sa[b], x[i]), __fmul_rn(sb[b], e[i]));               // ddpm.py:46
 }
 
-// to_rgb (C -> 3) + bilinear x2 accumulation of the previous stage's RGB (NCHW planes)
+// to_rgb (C -> OC channels; 3 in every script of the reference, vae.py:100-103 allows any) + bilinear x2 accumulation of the previous
+// stage's planes (NCHW)
+template <int OC>
 __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                        const float *__restrict__ bias, const float *__restrict__ prev,
                                                        float *__restrict__ out, int B, int H, int W, int C, int lpr)
@@ -360,26 +362,29 @@ __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__
     const int c4n = C >> 2;
     const bool live = row < rows;
     const f32x4 *xr = (const f32x4 *)(x + (live ? row : 0) * C);
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    float d[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) d[j] = 0.f;
     for (int c4 = sub; c4 < c4n; c4 += lpr) {
         const f32x4 v = live ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 w0 = ((const f32x4 *)w)[c4], w1 = ((const f32x4 *)(w + C))[c4], w2 = ((const f32x4 *)(w + 2 * C))[c4];
+        f32x4 wj[OC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            d0 = fmaf(v[e], w0[e], d0);
-            d1 = fmaf(v[e], w1[e], d1);
-            d2 = fmaf(v[e], w2[e], d2);
-        }
+        for (int j = 0; j < OC; ++j) wj[j] = ((const f32x4 *)(w + j * C))[c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < OC; ++j) d[j] = fmaf(v[e], wj[j][e], d[j]);
     }
-    d0 = group_sum(d0, lpr);
-    d1 = group_sum(d1, lpr);
-    d2 = group_sum(d2, lpr);
+#pragma unroll
+    for (int j = 0; j < OC; ++j) d[j] = group_sum(d[j], lpr);
     if (!live || sub != 0) return;
     const int HW = H * W;
     const long long b = row / HW;
     const int pix = (int)(row - b * HW);
     const int y = pix / W, xx = pix - y * W;
-    float r[3] = {d0 + bias[0], d1 + bias[1], d2 + bias[2]};
+    float r[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) r[j] = d[j] + bias[j];
     if (prev) {
         const int PH = H >> 1, PW = W >> 1;
         // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)  (vae.py:131)
@@ -391,15 +396,15 @@ __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__
         const float ly = sy - (float)y0, lx = sx - (float)x0;
         const float hy = 1.f - ly, hx = 1.f - lx;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float *pp = prev + (b * 3 + j) * PH * PW;
+        for (int j = 0; j < OC; ++j) {
+            const float *pp = prev + (b * OC + j) * PH * PW;
             const float top = hx * pp[y0 * PW + x0] + lx * pp[y0 * PW + x1];
             const float bot = hx * pp[y1 * PW + x0] + lx * pp[y1 * PW + x1];
             r[j] = (hy * top + ly * bot) + r[j];
         }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) out[(b * 3 + j) * HW + pix] = r[j];
+    for (int j = 0; j < OC; ++j) out[(b * OC + j) * HW + pix] = r[j];
 }
 
 // [B, R, Cc] -> [B, Cc, R] for any R, Cc (32x32 LDS tiles); used for NCHW <-> NHWC
@@ -546,14 +551,24 @@ extern "C" int ldm_qsample_f32(const float *x, const float *e, const float *sa, 
 
 extern "C" int ldm_rgb_head_f32(const float *x, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, void *stream)
 {
+    return ldm_rgb_head_oc_f32(x, w, bias, prev, out, B, H, W, C, 3, stream);
+}
+
+extern "C" int ldm_rgb_head_oc_f32(const float *x, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, int OC,
+                                   void *stream)
+{
     LDM_REQUIRE(x && w && bias && out, "ldm_rgb_head_f32: null pointer");
-    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "ldm_rgb_head_f32: bad shape");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && OC >= 1 && OC <= 4, "ldm_rgb_head_f32: bad shape (1 <= output channels <= 4)");
     LDM_REQUIRE(!prev || (H % 2 == 0 && W % 2 == 0), "ldm_rgb_head_f32: prev needs even H, W");
     LDM_REQUIRE(ldm_aligned16(x) && ldm_aligned16(w), "ldm_rgb_head_f32: unaligned pointer");
     const int lpr = pow2_lanes(C / 4) > 16 ? 16 : pow2_lanes(C / 4);
     const long long rows = (long long)B * H * W;
     const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
-    hipLaunchKernelGGL(rgb_head_kernel, dim3(blocks_for(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, prev, out, B, H, W, C, lpr);
+    const dim3 grid(blocks_for(waves, 4));
+    if (OC == 3) hipLaunchKernelGGL(rgb_head_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, prev, out, B, H, W, C, lpr);
+    else if (OC == 1) hipLaunchKernelGGL(rgb_head_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, prev, out, B, H, W, C, lpr);
+    else if (OC == 2) hipLaunchKernelGGL(rgb_head_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, prev, out, B, H, W, C, lpr);
+    else hipLaunchKernelGGL(rgb_head_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, prev, out, B, H, W, C, lpr);
     LDM_CHECK_LAUNCH("ldm_rgb_head_f32");
     return LDM_OK;
 }

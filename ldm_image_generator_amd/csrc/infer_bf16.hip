@@ -83,6 +83,7 @@ __device__ __forceinline__ float group_sum16(float v, int lpr)
 }
 
 // a group of `lpr` lanes owns one pixel; a lane reads 8 channels (16 bytes) per step
+template <int OC>
 __global__ __launch_bounds__(256) void rgb_head_bf16_kernel(const unsigned short *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                             const float *__restrict__ prev, float *__restrict__ out, int B, int H, int W, int C, int lpr)
 {
@@ -95,30 +96,33 @@ __global__ __launch_bounds__(256) void rgb_head_bf16_kernel(const unsigned short
     const int c8n = C >> 3;
     const bool live = row < rows;
     const u32x4 *xr = (const u32x4 *)(x + (live ? row : 0) * C);
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    float d[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) d[j] = 0.f;
     for (int c8 = sub; c8 < c8n; c8 += lpr) {
         const u32x4 v = live ? xr[c8] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const f32x4 w0 = ((const f32x4 *)w)[2 * c8 + hh], w1 = ((const f32x4 *)(w + C))[2 * c8 + hh], w2 = ((const f32x4 *)(w + 2 * C))[2 * c8 + hh];
+            f32x4 wj[OC];
+#pragma unroll
+            for (int j = 0; j < OC; ++j) wj[j] = ((const f32x4 *)(w + j * C))[2 * c8 + hh];
             const float xv[4] = {lo16(v[2 * hh]), hi16(v[2 * hh]), lo16(v[2 * hh + 1]), hi16(v[2 * hh + 1])};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                d0 = fmaf(xv[e], w0[e], d0);
-                d1 = fmaf(xv[e], w1[e], d1);
-                d2 = fmaf(xv[e], w2[e], d2);
-            }
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < OC; ++j) d[j] = fmaf(xv[e], wj[j][e], d[j]);
         }
     }
-    d0 = group_sum16(d0, lpr);
-    d1 = group_sum16(d1, lpr);
-    d2 = group_sum16(d2, lpr);
+#pragma unroll
+    for (int j = 0; j < OC; ++j) d[j] = group_sum16(d[j], lpr);
     if (!live || sub != 0) return;
     const int HW = H * W;
     const long long b = row / HW;
     const int pix = (int)(row - b * HW);
     const int y = pix / W, xx = pix - y * W;
-    float r[3] = {d0 + bias[0], d1 + bias[1], d2 + bias[2]};
+    float r[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) r[j] = d[j] + bias[j];
     if (prev) {
         const int PH = H >> 1, PW = W >> 1;
         // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)  (vae.py:131)
@@ -130,15 +134,15 @@ __global__ __launch_bounds__(256) void rgb_head_bf16_kernel(const unsigned short
         const float ly = sy - (float)y0, lx = sx - (float)x0;
         const float hy = 1.f - ly, hx = 1.f - lx;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float *pp = prev + (b * 3 + j) * PH * PW;
+        for (int j = 0; j < OC; ++j) {
+            const float *pp = prev + (b * OC + j) * PH * PW;
             const float top = hx * pp[y0 * PW + x0] + lx * pp[y0 * PW + x1];
             const float bot = hx * pp[y1 * PW + x0] + lx * pp[y1 * PW + x1];
             r[j] = (hy * top + ly * bot) + r[j];
         }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) out[(b * 3 + j) * HW + pix] = r[j];
+    for (int j = 0; j < OC; ++j) out[(b * OC + j) * HW + pix] = r[j];
 }
 
 // fine[(b, y, x), :] = coarse[(b, y / 2, x / 2), :] + skip[(b, y, x), :]; one float4 per thread
@@ -217,16 +221,26 @@ extern "C" int ldm_depth_to_space2_bf16(const void *in_bf16, void *out_bf16, int
 
 extern "C" int ldm_rgb_head_bf16(const void *x_bf16, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, void *stream)
 {
+    return ldm_rgb_head_oc_bf16(x_bf16, w, bias, prev, out, B, H, W, C, 3, stream);
+}
+
+extern "C" int ldm_rgb_head_oc_bf16(const void *x_bf16, const float *w, const float *bias, const float *prev, float *out, int B, int H, int W, int C, int OC,
+                                    void *stream)
+{
     LDM_REQUIRE(x_bf16 && w && bias && out, "ldm_rgb_head_bf16: null pointer");
-    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "ldm_rgb_head_bf16: bad shape (C %% 8 == 0)");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0 && OC >= 1 && OC <= 4, "ldm_rgb_head_bf16: bad shape (C %% 8 == 0, 1 <= output channels <= 4)");
     LDM_REQUIRE(!prev || (H % 2 == 0 && W % 2 == 0), "ldm_rgb_head_bf16: prev needs even H, W");
     LDM_REQUIRE(ldm_aligned16(x_bf16) && ldm_aligned16(w) && (C % 4 == 0), "ldm_rgb_head_bf16: unaligned pointer");
     int lpr = pow2_floor(C / 8);
     lpr = lpr > 8 ? 8 : lpr;
     const long long rows = (long long)B * H * W;
     const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
-    hipLaunchKernelGGL(rgb_head_bf16_kernel, dim3(blocks_of(waves, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_bf16, w, bias, prev, out, B, H,
-                       W, C, lpr);
+    const dim3 grid(blocks_of(waves, 4));
+    const unsigned short *x16 = (const unsigned short *)x_bf16;
+    if (OC == 3) hipLaunchKernelGGL(rgb_head_bf16_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x16, w, bias, prev, out, B, H, W, C, lpr);
+    else if (OC == 1) hipLaunchKernelGGL(rgb_head_bf16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x16, w, bias, prev, out, B, H, W, C, lpr);
+    else if (OC == 2) hipLaunchKernelGGL(rgb_head_bf16_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x16, w, bias, prev, out, B, H, W, C, lpr);
+    else hipLaunchKernelGGL(rgb_head_bf16_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x16, w, bias, prev, out, B, H, W, C, lpr);
     LDM_CHECK_LAUNCH("ldm_rgb_head_bf16");
     return LDM_OK;
 }

@@ -52,6 +52,7 @@ __global__ void space_to_depth2_kernel(const f32x4 *__restrict__ fine, f32x4 *__
 }
 
 // rgb head backward, per pixel: drows[p][c] (+)= sum_j drgb[b][j][pix] w[j][c]
+template <int OC>
 __global__ __launch_bounds__(256) void rgb_head_bwd_kernel(const float *__restrict__ drgb, const float *__restrict__ w, float *__restrict__ drows,
                                                            int B, int H, int W, int C, int accumulate)
 {
@@ -61,13 +62,22 @@ __global__ __launch_bounds__(256) void rgb_head_bwd_kernel(const float *__restri
     const int HW = H * W;
     const long long b = row / HW;
     const int pix = (int)(row - b * HW);
-    const float g0 = drgb[(b * 3 + 0) * HW + pix], g1 = drgb[(b * 3 + 1) * HW + pix], g2 = drgb[(b * 3 + 2) * HW + pix];
+    float gj[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) gj[j] = drgb[(b * OC + j) * HW + pix];
     f32x4 *dr = (f32x4 *)(drows + row * C);
     for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
-        const f32x4 w0 = ((const f32x4 *)w)[c4], w1 = ((const f32x4 *)(w + C))[c4], w2 = ((const f32x4 *)(w + 2 * C))[c4];
+        f32x4 wj[OC];
+#pragma unroll
+        for (int j = 0; j < OC; ++j) wj[j] = ((const f32x4 *)(w + j * C))[c4];
         f32x4 o = accumulate ? dr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += (g0 * w0[e] + g1 * w1[e]) + g2 * w2[e];
+        for (int e = 0; e < 4; ++e) {
+            float t = gj[0] * wj[0][e];                               // ((g0 w0 + g1 w1) + g2 w2) + ...
+#pragma unroll
+            for (int j = 1; j < OC; ++j) t = t + gj[j] * wj[j][e];
+            o[e] += t;
+        }
         dr[c4] = o;
     }
 }
@@ -75,11 +85,11 @@ __global__ __launch_bounds__(256) void rgb_head_bwd_kernel(const float *__restri
 // The adjoint of the bilinear x2 accumulation (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False), vae.py:131) as a
 // GATHER: a thread owns one coarse cell (b, j, py, px) and walks the fine pixels that can touch it (rows 2 py - 2 ... 2 py + 3, same
 // for columns) in a fixed order, adding the corner weights of those whose source cell it is.  No atomics: bit-reproducible.
-__global__ __launch_bounds__(256) void bilinear2x_adjoint_kernel(const float *__restrict__ drgb, float *__restrict__ dprev, int B, int H, int W)
+__global__ __launch_bounds__(256) void bilinear2x_adjoint_kernel(const float *__restrict__ drgb, float *__restrict__ dprev, int B, int H, int W, int OC)
 {
     const int PH = H >> 1, PW = W >> 1;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)B * 3 * PH * PW) return;
+    if (i >= (long long)B * OC * PH * PW) return;
     const int px = (int)(i % PW);
     const int py = (int)((i / PW) % PH);
     const long long bj = i / ((long long)PW * PH);
@@ -113,50 +123,50 @@ __global__ __launch_bounds__(256) void bilinear2x_adjoint_kernel(const float *__
 }
 
 // dw[j][c] = sum_p drgb[p][j] rows[p][c], db[j] = sum_p drgb[p][j]: a block sums its slab of pixels into ITS plane of `parts`
-// ([blocks][3 C + 3]: weight sums, then the three bias sums); sum_planes_kernel adds the planes in block order (no atomics)
+// ([blocks][OC C + OC]: weight sums, then the bias sums); sum_planes_kernel adds the planes in block order (no atomics)
+template <int OC>
 __global__ __launch_bounds__(256) void rgb_head_wgrad_kernel(const float *__restrict__ drgb, const float *__restrict__ rows, float *__restrict__ parts,
                                                              int B, int HW, int C, int slab)
 {
-    float *dw = parts + (long long)blockIdx.x * (3 * C + 3);
-    float *db = dw + 3 * C;
+    float *dw = parts + (long long)blockIdx.x * (OC * C + OC);
+    float *db = dw + OC * C;
     const long long total = (long long)B * HW;
     const long long p0 = (long long)blockIdx.x * slab;
     const long long p1 = p0 + slab < total ? p0 + slab : total;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        float a[OC], sm[OC];
+#pragma unroll
+        for (int j = 0; j < OC; ++j) a[j] = sm[j] = 0.f;
         for (long long p = p0; p < p1; ++p) {
             const long long b = p / HW;
             const int pix = (int)(p - b * HW);
-            const float g0 = drgb[(b * 3 + 0) * HW + pix], g1 = drgb[(b * 3 + 1) * HW + pix], g2 = drgb[(b * 3 + 2) * HW + pix];
             const float v = rows[p * C + c];
-            a0 = fmaf(g0, v, a0);
-            a1 = fmaf(g1, v, a1);
-            a2 = fmaf(g2, v, a2);
-            s0 += g0;
-            s1 += g1;
-            s2 += g2;
+#pragma unroll
+            for (int j = 0; j < OC; ++j) {
+                const float g = drgb[(b * OC + j) * HW + pix];
+                a[j] = fmaf(g, v, a[j]);
+                sm[j] += g;
+            }
         }
-        dw[c] = a0;
-        dw[C + c] = a1;
-        dw[2 * C + c] = a2;
+#pragma unroll
+        for (int j = 0; j < OC; ++j) dw[j * C + c] = a[j];
         if (c == 0) {
-            db[0] = s0;
-            db[1] = s1;
-            db[2] = s2;
+#pragma unroll
+            for (int j = 0; j < OC; ++j) db[j] = sm[j];
         }
     }
 }
 
 // dw[i] (i < 3 C) and db[i - 3 C] = sum over planes of parts[plane][i], in plane order
-__global__ __launch_bounds__(256) void sum_planes_kernel(const float *__restrict__ parts, int nplanes, int C, float *__restrict__ dw, float *__restrict__ db)
+__global__ __launch_bounds__(256) void sum_planes_kernel(const float *__restrict__ parts, int nplanes, int C, float *__restrict__ dw, float *__restrict__ db, int OC)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n = 3 * C + 3;
+    const int n = OC * C + OC;
     if (i >= n) return;
     float s = 0.f;
     for (int k = 0; k < nplanes; ++k) s += parts[(long long)k * n + i];
-    if (i < 3 * C) dw[i] = s;
-    else db[i - 3 * C] = s;
+    if (i < OC * C) dw[i] = s;
+    else db[i - OC * C] = s;
 }
 
 }  // namespace
@@ -197,21 +207,38 @@ extern "C" int ldm_space_to_depth2_f32(const float *fine, float *out, int B, int
 extern "C" int ldm_rgb_head_bwd_f32(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *dprev, float *dw,
                                     float *db, int B, int H, int W, int C, void *stream)
 {
+    return ldm_rgb_head_bwd_oc_f32(drgb, w, rows, drows, accumulate, dprev, dw, db, B, H, W, C, 3, stream);
+}
+
+template <int OC>
+static void rgb_head_bwd_launch(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *parts, unsigned nb, int slab,
+                                int B, int H, int W, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(rgb_head_bwd_kernel<OC>, dim3(vb_blocks((long long)B * H * W, 4)), dim3(256), 0, st, drgb, w, drows, B, H, W, C, accumulate);
+    hipLaunchKernelGGL(rgb_head_wgrad_kernel<OC>, dim3(nb), dim3(256), 0, st, drgb, rows, parts, B, H * W, C, slab);
+}
+
+extern "C" int ldm_rgb_head_bwd_oc_f32(const float *drgb, const float *w, const float *rows, float *drows, int accumulate, float *dprev, float *dw,
+                                       float *db, int B, int H, int W, int C, int OC, void *stream)
+{
     LDM_REQUIRE(drgb && w && rows && drows && dw && db, "ldm_rgb_head_bwd_f32: null pointer");
-    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (!dprev || (H % 2 == 0 && W % 2 == 0)), "ldm_rgb_head_bwd_f32: bad shape");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && OC >= 1 && OC <= 4 && (!dprev || (H % 2 == 0 && W % 2 == 0)),
+                "ldm_rgb_head_bwd_f32: bad shape (1 <= output channels <= 4)");
     LDM_REQUIRE(ldm_aligned16(w) && ldm_aligned16(drows), "ldm_rgb_head_bwd_f32: unaligned pointer");
     const long long rowsn = (long long)B * H * W;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(rgb_head_bwd_kernel, dim3(vb_blocks(rowsn, 4)), dim3(256), 0, st, drgb, w, drows, B, H, W, C, accumulate);
     if (dprev)
-        hipLaunchKernelGGL(bilinear2x_adjoint_kernel, dim3(vb_blocks((long long)B * 3 * (H / 2) * (W / 2), 256)), dim3(256), 0, st, drgb, dprev, B, H, W);
+        hipLaunchKernelGGL(bilinear2x_adjoint_kernel, dim3(vb_blocks((long long)B * OC * (H / 2) * (W / 2), 256)), dim3(256), 0, st, drgb, dprev, B, H, W, OC);
     long long slab = (rowsn + 511) / 512;                                 // at most ~512 planes for the fixed-order sum
     slab = slab < 256 ? 256 : slab;
     const unsigned nb = vb_blocks(rowsn, (int)slab);
-    float *parts = (float *)ldm_scratch(st, (size_t)nb * (3 * C + 3) * sizeof(float));
+    float *parts = (float *)ldm_scratch(st, (size_t)nb * (OC * C + OC) * sizeof(float));
     if (!parts) return LDM_ELAUNCH;
-    hipLaunchKernelGGL(rgb_head_wgrad_kernel, dim3(nb), dim3(256), 0, st, drgb, rows, parts, B, H * W, C, (int)slab);
-    hipLaunchKernelGGL(sum_planes_kernel, dim3((3 * C + 3 + 255) / 256), dim3(256), 0, st, (const float *)parts, (int)nb, C, dw, db);
+    if (OC == 3) rgb_head_bwd_launch<3>(drgb, w, rows, drows, accumulate, parts, nb, (int)slab, B, H, W, C, st);
+    else if (OC == 1) rgb_head_bwd_launch<1>(drgb, w, rows, drows, accumulate, parts, nb, (int)slab, B, H, W, C, st);
+    else if (OC == 2) rgb_head_bwd_launch<2>(drgb, w, rows, drows, accumulate, parts, nb, (int)slab, B, H, W, C, st);
+    else rgb_head_bwd_launch<4>(drgb, w, rows, drows, accumulate, parts, nb, (int)slab, B, H, W, C, st);
+    hipLaunchKernelGGL(sum_planes_kernel, dim3((OC * C + OC + 255) / 256), dim3(256), 0, st, (const float *)parts, (int)nb, C, dw, db, OC);
     LDM_CHECK_LAUNCH("ldm_rgb_head_bwd_f32");
     return LDM_OK;
 }

@@ -174,9 +174,10 @@ def qsample(x, e, sa, sb, out):
 
 
 def rgb_head(x, w, bias, prev, out, B, H, W, C):
+    """to_rgb [OC, C] + bilinear x2 accumulation of ``prev`` [B, OC, H/2, W/2] into ``out`` [B, OC, H, W]; OC = w.shape[0] (1..4)."""
     lib = _lib.load()
-    _lib.check(lib.ldm_rgb_head_f32(_dev(x, "x"), _dev(w, "w"), _dev(bias, "bias"), _opt(prev, "prev"), _dev(out, "out"),
-                                    B, H, W, C, _stream()), "ldm_rgb_head_f32")
+    _lib.check(lib.ldm_rgb_head_oc_f32(_dev(x, "x"), _dev(w, "w"), _dev(bias, "bias"), _opt(prev, "prev"), _dev(out, "out"),
+                                       B, H, W, C, w.shape[0], _stream()), "ldm_rgb_head_oc_f32")
     return out
 
 
@@ -533,8 +534,8 @@ def space_to_depth2(fine, B, H, W, C):
 
 
 def rgb_head_bwd(drgb, w, rows, drows, accumulate, dprev, dw, db, B, H, W, C):
-    _call("ldm_rgb_head_bwd_f32", _dev(drgb, "drgb"), _dev(w, "w"), _dev(rows, "rows"), _dev(drows, "drows"), int(bool(accumulate)),
-          _opt(dprev, "dprev"), _dev(dw, "dw"), _dev(db, "db"), B, H, W, C)
+    _call("ldm_rgb_head_bwd_oc_f32", _dev(drgb, "drgb"), _dev(w, "w"), _dev(rows, "rows"), _dev(drows, "drows"), int(bool(accumulate)),
+          _opt(dprev, "dprev"), _dev(dw, "dw"), _dev(db, "db"), B, H, W, C, w.shape[0])
 
 
 def vq_loss_bwd(x_rows, e_rows, idx, gscale, n_emb):
@@ -606,7 +607,7 @@ def depth_to_space2_bf16(x16, B, H, W, C):
 
 
 def rgb_head_bf16(x16, w, bias, prev, out, B, H, W, C):
-    _call("ldm_rgb_head_bf16", _dev(x16, "x", BF16), _dev(w, "w"), _dev(bias, "bias"), _opt(prev, "prev"), _dev(out, "out"), B, H, W, C)
+    _call("ldm_rgb_head_oc_bf16", _dev(x16, "x", BF16), _dev(w, "w"), _dev(bias, "bias"), _opt(prev, "prev"), _dev(out, "out"), B, H, W, C, w.shape[0])
     return out
 
 

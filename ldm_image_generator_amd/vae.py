@@ -157,8 +157,8 @@ class Encoder(nn.Module):
 class DecoderStack(nn.Module):
     def __init__(self, channels, num_layers, output_channels=3):
         super().__init__()
-        if output_channels != 3:
-            raise NotImplementedError("the fused to_rgb kernel is specialised for 3 output channels")
+        if not 1 <= output_channels <= 4:
+            raise NotImplementedError("the fused to_rgb kernel handles 1 to 4 output channels (got %r)" % (output_channels,))
         self.layers = nn.Sequential(*[ResBlock(channels) for _ in range(num_layers)])
         self.to_rgb = nn.Conv2d(channels, output_channels, 1, 1, 0)
 
@@ -166,7 +166,7 @@ class DecoderStack(nn.Module):
         for blk in self.layers:
             rows = blk.forward_rows(rows, shape)
         b, h, w = shape
-        rgb = torch.empty(b, 3, h, w, device=rows.device, dtype=torch.float32)
+        rgb = torch.empty(b, self.to_rgb.weight.shape[0], h, w, device=rows.device, dtype=torch.float32)
         head = ops.rgb_head_bf16 if rows.dtype == torch.bfloat16 else ops.rgb_head
         head(rows, w2d(self.to_rgb), self.to_rgb.bias.detach(), prev_rgb, rgb, b, h, w, rows.shape[1])
         return rows, rgb

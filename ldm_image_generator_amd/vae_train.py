@@ -100,7 +100,7 @@ class DecoderFunction(torch.autograd.Function):
             shape = (b, h, w)
             for blk in stage.layers:
                 rows = _resblock_forward(blk, rows, shape, rec["blocks"])
-            new_rgb = torch.empty(b, 3, h, w, device=dev, dtype=torch.float32)
+            new_rgb = torch.empty(b, stage.to_rgb.weight.shape[0], h, w, device=dev, dtype=torch.float32)
             ops.rgb_head(rows, w2d(stage.to_rgb), stage.to_rgb.bias.detach(), rgb, new_rgb, b, h, w, rows.shape[1])
             rec.update(stage=stage, rows=rows, shape=shape, has_prev=rgb is not None)
             tape.append(rec)
@@ -118,9 +118,10 @@ class DecoderFunction(torch.autograd.Function):
         for rec in reversed(tape):
             stage, rows, (b, h, w) = rec["stage"], rec["rows"], rec["shape"]
             c = rows.shape[1]
-            dw_rgb = torch.zeros(3, c, device=dev, dtype=torch.float32)
-            db_rgb = torch.zeros(3, device=dev, dtype=torch.float32)
-            dprev = torch.zeros(b, 3, h // 2, w // 2, device=dev, dtype=torch.float32) if rec["has_prev"] else None
+            oc = stage.to_rgb.weight.shape[0]
+            dw_rgb = torch.zeros(oc, c, device=dev, dtype=torch.float32)
+            db_rgb = torch.zeros(oc, device=dev, dtype=torch.float32)
+            dprev = torch.zeros(b, oc, h // 2, w // 2, device=dev, dtype=torch.float32) if rec["has_prev"] else None
             accumulate = drows is not None
             if drows is None:
                 drows = torch.empty_like(rows)

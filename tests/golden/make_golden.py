@@ -378,6 +378,24 @@ def decoder_bwd_cases():
     save("decoder_bwd", **arrs)
 
 
+def decoder_oc_cases():
+    """Decoder(output_channels=4) and (=1) (vae.py:100-114; every script uses 3): output, dL/dz and every parameter-gradient norm of
+    loss = sum(y * g) through the reference's autograd."""
+    arrs = {}
+    for oc in (4, 1):
+        dec = load_formula(ref_vae.Decoder(output_channels=oc, channels=[64, 32], stages=[1, 1]), salt=6)
+        z = g("decoc.z%d" % oc, (2, 8, 8, 4)).clone().requires_grad_()
+        y = dec(z)
+        gy = g("decoc.g%d" % oc, tuple(y.shape))
+        (y * gy).sum().backward()
+        names = [k for k, p_ in dec.named_parameters() if p_.grad is not None]
+        pd = dict(dec.named_parameters())
+        arrs.update({"z_%d" % oc: z.detach(), "g_%d" % oc: gy, "y_%d" % oc: y.detach(), "dz_%d" % oc: z.grad, "names_%d" % oc: np.array(names),
+                     "gradnorms_%d" % oc: np.asarray([float(pd[k].grad.double().norm()) for k in names]),
+                     "grad_to_rgb_%d" % oc: dec.stages[0].to_rgb.weight.grad, "grad_to_rgb_bias_%d" % oc: dec.stages[1].to_rgb.bias.grad})
+    save("decoder_oc", **arrs)
+
+
 def vae_bwd_cases():
     """VAE.calclate_loss (vae.py:36-43) WITH gradients through the reference's autograd: (loss_recon + loss_reg).backward() on a tiny
     encoder / decoder / 512-entry codebook, latent noise replayed; norm + a corner of every parameter gradient."""
@@ -519,6 +537,9 @@ def stem_cases():
 
 
 if __name__ == "__main__":
+    if "--decoder-oc-only" in sys.argv:
+        decoder_oc_cases()
+        sys.exit(0)
     if "--stem-only" in sys.argv:
         stem_cases()
         sys.exit(0)
@@ -545,6 +566,7 @@ if __name__ == "__main__":
     sample_cases(tiny, full)
     loss_cases(tiny)
     stem_cases()
+    decoder_oc_cases()
     loss_full_cases()
     vae_cases()
     encoder_cases()

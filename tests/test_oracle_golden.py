@@ -215,6 +215,16 @@ def test_res_block_and_decoder():
     assert rel_l2(y, T(g["y"])) < TOL
 
 
+@pytest.mark.parametrize("oc", [4, 1])
+def test_decoder_output_channels(oc):
+    """Decoder(output_channels=oc) (vae.py:100-114)."""
+    g = load_golden("decoder_oc")
+    sd = O.formula_state(O.decoder_state_shapes(output_channels=oc, channels=(64, 32), stages=(1, 1)), salt=6)
+    with torch.no_grad():
+        y = O.vae_decode(sd, T(g["z_%d" % oc]), stages=(1, 1))
+    assert y.shape == tuple(g["y_%d" % oc].shape) and rel_l2(y, T(g["y_%d" % oc])) < TOL
+
+
 def test_decoder_full_size():
     g = load_golden("decoder_full")
     shapes = O.decoder_state_shapes()
