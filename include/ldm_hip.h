@@ -434,6 +434,10 @@ typedef struct ldm_cast_job {
 int ldm_gconv_pack_bf16(const float *w, void *fwd_bf16, void *rot_bf16, int C, void *stream);
 /* out[r][0..n) = src[0..n) for r < reps (one gradient shared by several biases, as separate rows) */
 int ldm_replicate_f32(const float *src, float *out, int n, int reps, void *stream);
+/* dense 3x3 conv.weight [Cout, Cin, 3, 3] -> the forward matrix fwd [Cout][tap * Cin + ci] (LDM_A_CONV3X3's column order) and the
+ * data-gradient matrix dgrad [Cin][tap' * Cout + co] with tap' = 8 - tap (the mirrored filter, in / out swapped: vae.py:57-58's autograd)
+ * in one launch; either output may be NULL */
+int ldm_pack3x3_f32(const float *w, float *fwd, float *dgrad, int Cout, int Cin, void *stream);
 size_t ldm_multi_cast_table_bytes(int njobs);
 int ldm_multi_cast_bf16(const ldm_cast_job *items, int njobs, void *table_dev, int rebuild, long long *tiles_io, void *stream);
 

@@ -180,6 +180,7 @@ SIGNATURES = {
     "ldm_rgb_head_bwd_oc_f32": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ldm_gconv_pack_bf16": (_I, [_P, _P, _P, _I, _P]),
     "ldm_replicate_f32": (_I, [_P, _P, _I, _I, _P]),
+    "ldm_pack3x3_f32": (_I, [_P, _P, _P, _I, _I, _P]),
     "ldm_multi_cast_table_bytes": (ctypes.c_size_t, [_I]),
     "ldm_multi_cast_bf16": (_I, [ctypes.POINTER(CastJob), _I, _P, _I, ctypes.POINTER(_L), _P]),
     "ldm_film_hidden": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -632,6 +632,16 @@ def gconv_pack_bf16(w, fwd16, rot16):
     _call("ldm_gconv_pack_bf16", _dev(w, "w"), _dev(fwd16, "fwd", BF16), _dev(rot16, "rot", BF16), w.shape[0])
 
 
+def pack3x3(w, want_dgrad=True):
+    """(forward matrix [Cout, 9 Cin], data-gradient matrix [Cin, 9 Cout] or None) of a dense 3x3 conv weight [Cout, Cin, 3, 3]: one launch."""
+    w = w.detach().contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    fwd = torch.empty(cout, 9 * cin, device=w.device, dtype=torch.float32)
+    dgrad = torch.empty(cin, 9 * cout, device=w.device, dtype=torch.float32) if want_dgrad else None
+    _call("ldm_pack3x3_f32", _dev(w, "w"), _dev(fwd, "fwd"), _opt(dgrad, "dgrad"), cout, cin)
+    return fwd, dgrad
+
+
 def replicate(src, reps):
     """-> [reps, n] fp32: ``reps`` separate copies of the vector ``src`` in one launch."""
     n = src.numel()

@@ -21,14 +21,6 @@ SLOPE = 0.01            # F.leaky_relu's default negative_slope (vae.py:62,64)
 IMPLICIT_WGRAD = True   # dense 3x3 weight gradients without the im2col matrix (False: explicit im2col + TN / NT GEMM, the round-2 form)
 
 
-def _pack3x3(w):        # [Cout, Cin, 3, 3] -> [Cout][tap][Cin]
-    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
-
-
-def _pack3x3_dgrad(w):  # filter of the data gradient: [Cin][tap'][Cout] with tap' = the mirrored tap
-    return w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], 9 * w.shape[0]).contiguous()
-
-
 def _conv(rows, shape, packed, bias, cin, cout, act, addend=None):
     b, h, w = shape
     out = torch.empty(rows.shape[0], cout, device=rows.device, dtype=torch.float32)
@@ -57,9 +49,11 @@ def _conv_grads(dy, x, shape, conv, grads):
 def _resblock_forward(blk, rows, shape, tape):
     """x + lrelu(c2(lrelu(c1(x))))  (vae.py:60-66) keeping x, the activated hidden and the activated branch."""
     c = rows.shape[1]
-    y1 = _conv(rows, shape, _pack3x3(blk.c1.weight), blk.c1.bias.detach(), c, c, ops.ACT_LRELU)
-    t2 = _conv(y1, shape, _pack3x3(blk.c2.weight), blk.c2.bias.detach(), c, c, ops.ACT_LRELU)
-    tape.append(dict(blk=blk, x=rows, y1=y1, t2=t2))
+    p1, q1 = ops.pack3x3(blk.c1.weight)                  # forward and data-gradient filter matrices: one launch per conv
+    p2, q2 = ops.pack3x3(blk.c2.weight)
+    y1 = _conv(rows, shape, p1, blk.c1.bias.detach(), c, c, ops.ACT_LRELU)
+    t2 = _conv(y1, shape, p2, blk.c2.bias.detach(), c, c, ops.ACT_LRELU)
+    tape.append(dict(blk=blk, x=rows, y1=y1, t2=t2, q1=q1, q2=q2))
     return ops.add_(t2.clone(), rows)
 
 
@@ -68,10 +62,10 @@ def _resblock_backward(rec, drows, shape, grads):
     c = x.shape[1]
     d2 = ops.lrelu_bwd(drows, t2, SLOPE)                                  # at c2's pre-activation
     _conv_grads(d2, y1, shape, blk.c2, grads)
-    dy1 = _conv(d2, shape, _pack3x3_dgrad(blk.c2.weight), None, c, c, ops.ACT_NONE)
+    dy1 = _conv(d2, shape, rec["q2"], None, c, c, ops.ACT_NONE)
     d1 = ops.lrelu_bwd(dy1, y1, SLOPE)
     _conv_grads(d1, x, shape, blk.c1, grads)
-    return _conv(d1, shape, _pack3x3_dgrad(blk.c1.weight), None, c, c, ops.ACT_NONE, addend=drows)          # + the skip path
+    return _conv(d1, shape, rec["q1"], None, c, c, ops.ACT_NONE, addend=drows)          # + the skip path
 
 
 class DecoderFunction(torch.autograd.Function):
