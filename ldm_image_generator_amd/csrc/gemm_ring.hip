@@ -202,6 +202,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     };
 
     // ---- prologue: the whole ring in flight, then step 0's first slice into registers ---------------------------------------------
+#ifdef LDM_RING_PRIO                                     // probe: static priority for the younger wave group (MI355X_MICROARCH.md, two waves per SIMD)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(LDM_RING_PRIO);
+#endif
     loader_setup();
 #pragma unroll 1
     for (int s0 = 0; s0 < RNS; ++s0) {
