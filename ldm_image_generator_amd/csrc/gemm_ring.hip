@@ -404,14 +404,26 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                 // run-time "is there an addend" flag, which made it wait in every instance) each fragment waited for the previous
                 // fragment's stores to be acknowledged -- 4.7 us per tile, all of the epilogue's measured cost.
                 // (half fragments = 16 rows at a time: two 16-register addend buffers did not fit beside 128 accumulators)
-                f32x4 ad[2][2];
+                // 256 x 128 tiles (64 accumulator registers) have room for the WHOLE tile's addend: all 16 loads go out at the top of the
+                // epilogue.  In-kernel stamps at M = 262144, N = 128, K = 384 (K loop 107 k cycles = 4.4 k per step, 92 % of them MFMA
+                // issue, at a 2.05 GHz shader clock): epilogue 10.5 k cycles with the one-ahead prefetch, 8.5 k with this, 4 k without
+                // an addend -- what is left is the bandwidth of 256 workgroups reading and writing their 128 KiB at the same moment,
+                // not latency (the launch: 239 -> 237 us)
+                constexpr bool ADD_ALL = ADD && NJ == 1;
+                constexpr int NAD = ADD_ALL ? 2 * NFR : 2;
+                f32x4 ad[NAD][2];
                 auto load_add = [&](int hh) {                 // half fragment hh = 2 f + kh: row pieces 2 kh, 2 kh + 1 of fragment f
                     const int f = hh >> 1, kh = hh & 1;
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
-                        ad[hh & 1][k] = *(const f32x4 *)(p.addend + (orow0 + (f / NJO) * 32 + 8 * (2 * kh + k) + rrow) * lda_ + col_of(f));
+                        ad[ADD_ALL ? hh : (hh & 1)][k] = *(const f32x4 *)(p.addend + (orow0 + (f / NJO) * 32 + 8 * (2 * kh + k) + rrow) * lda_ + col_of(f));
                 };
-                if constexpr (ADD) load_add(0);
+                if constexpr (ADD_ALL) {
+#pragma unroll
+                    for (int hh = 0; hh < 2 * NFR; ++hh) load_add(hh);
+                } else if constexpr (ADD) {
+                    load_add(0);
+                }
 #pragma unroll
                 for (int f = 0; f < NFR; ++f) {
                     const int i = f / NJO, j = f % NJO;
@@ -427,11 +439,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
 #pragma unroll
                         for (int k = 0; k < 2; ++k) v[k] = *(const f32x4 *)(scr + (8 * (2 * kh + k) + rsub) * 128 + cc * 16);
                         if constexpr (ADD) {
-                            if (hh + 1 < 2 * NFR) load_add(hh + 1);
+                            if constexpr (!ADD_ALL) {
+                                if (hh + 1 < 2 * NFR) load_add(hh + 1);
+                            }
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) v[k][q] += ad[hh & 1][k][q];
+                                for (int q = 0; q < 4; ++q) v[k][q] += ad[ADD_ALL ? hh : (hh & 1)][k][q];
                         }
 #pragma unroll
                         for (int k = 0; k < 2; ++k) *(f32x4 *)(o32 + (orow0 + i * 32 + 8 * (2 * kh + k) + rrow) * ldo_ + col_of(f)) = v[k];
