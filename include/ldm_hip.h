@@ -125,6 +125,11 @@ int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
  * each fp32 operand value is cut exactly into three bf16 pieces in registers and a product is six
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-level error, not bit-identical to 0/1; shapes it does
  * not cover run as 1).  Opt-in, process-wide; returns the previous setting (any other v only queries). */
+/* ReGLU forward of the fp32 training step in one launch (unet.py:14-15 and what its autograd keeps): d as for ldm_gemm_f32 with
+ * act = LDM_ACT_GATE, rows in, rows out, no addend; out = (A Wa^T + ba) * relu(A Wb^T + bb) and a_pre, b_pre = the two pre-activations, all
+ * fp32 [M, ldo].  Bit-identical to two plain ldm_gemm_f32 launches + ldm_gate_fwd_f32.  Returns 0 when launched, 1 when no kernel
+ * instance takes the shape (nothing was launched: run the three launches instead), negative on error. */
+int ldm_gemm_f32_gate_fwd(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream);
 int ldm_gemm_variant(int v);
 /* epilogue of the stream schedule for plain-rows outputs: 1 (default) = through LDS, 16 bytes per lane per store;
  * 0 = direct from the MFMA layout, 4 bytes per lane.  Bit-identical results; A/B knob.  Returns the previous setting. */

@@ -332,7 +332,22 @@ extern "C" int ldm_gemm_variant(int v)
     return old;
 }
 
-extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
+static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream);
+
+extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream) { return gemm_f32_impl(d, nullptr, nullptr, stream); }
+
+// ReGLU forward of the fp32 training step in ONE launch: out = (A Wa^T + ba) * relu(A Wb^T + bb) AND a_pre / b_pre (the two
+// pre-activations its backward needs), all fp32 [M, ldo].  d as for ldm_gemm_f32 with act = LDM_ACT_GATE, rows in, rows out, no addend.
+// Returns LDM_OK when launched, 1 when no kernel instance takes the shape (the caller then runs two plain GEMMs + ldm_gate_fwd_f32).
+extern "C" int ldm_gemm_f32_gate_fwd(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream)
+{
+    LDM_REQUIRE(d && a_pre && b_pre, "ldm_gemm_f32_gate_fwd: null pointer");
+    LDM_REQUIRE(d->act == LDM_ACT_GATE && !d->addend && d->a_mode == LDM_A_ROWS && d->o_mode == LDM_O_ROWS, "ldm_gemm_f32_gate_fwd: gated rows problem without addend only");
+    LDM_REQUIRE(ldm_aligned16(a_pre) && ldm_aligned16(b_pre) && ldm_aligned16(d->out) && d->ldo % 4 == 0, "ldm_gemm_f32_gate_fwd: outputs must be 16-byte addressable");
+    return gemm_f32_impl(d, a_pre, b_pre, stream);
+}
+
+static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream)
 {
     LDM_REQUIRE(d != nullptr, "ldm_gemm_f32: null descriptor");
     LDM_REQUIRE(d->a && d->out, "ldm_gemm_f32: null operand");
@@ -403,7 +418,17 @@ extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream)
     const double o_elems = (double)d->M * d->N * groups * (d->o_mode == LDM_O_UP2 ? 4.0 : 1.0);
     const double algo_bytes = 4.0 * (a_elems + (double)d->N * d->K * groups * (gate ? 2.0 : 1.0) + o_elems * (d->addend ? 2.0 : 1.0));
     LDM_REQUIRE(!(gate && d->a_mode == LDM_A_CONV3X3), "ldm_gemm_f32: GATE with conv3x3 unsupported");       // before the profiler opens a record
-    void *rec = ldm_prof_begin(LDM_PROF_GEMM, 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0), st, algo_bytes);
+    void *rec = ldm_prof_begin(LDM_PROF_GEMM, 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0), st,
+                               algo_bytes + (a_pre ? 8.0 * o_elems : 0.0));
+    if (a_pre) {                                                  // hidden + both pre-activations: the ring kernel's gated instance or nothing
+        p.out2 = a_pre;
+        p.out3 = b_pre;
+        const int taken = g_variant == 1 ? ldm_gemm_ring_dispatch_f32(p, groups, true, d->a_mode, st) : 0;
+        ldm_prof_end(rec, st);
+        if (!taken) return 1;
+        LDM_CHECK_LAUNCH("ldm_gemm_f32_gate_fwd");
+        return LDM_OK;
+    }
     if (!(d->workspace && splitk_launch(*d, p, gate, st))) launch_any(p, groups, gate, d->a_mode, st);
     ldm_prof_end(rec, st);
     LDM_CHECK_LAUNCH("ldm_gemm_f32");

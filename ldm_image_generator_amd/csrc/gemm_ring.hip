@@ -81,7 +81,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     constexpr int BN = GATE ? 128 : 128 * NJ;                      // output columns per tile
     constexpr int RPW = 2 + NJ;                                    // LDS-DMA instructions per wave and step (2 x A, NJ x W)
     constexpr int NM = (ET ? 1 : 4) * 4 * NJ;                      // MFMAs of one slice
-    static_assert(!GF || (ET == 1 && GATE && !OBF && !ADD), "bf16 gate forward with saved pre-activations: the gated bf16 instance");
+    static_assert(!GF || (GATE && !OBF && !ADD), "gate forward with saved pre-activations: a gated instance");
+    static_assert(!GF || ET == 1 || GF == 3, "fp32: hidden + both pre-activations (the training forward) or the plain gated instance");
     constexpr int NSTORE = GF ? 16 * GF : (OBF || GATE) ? 16 : 16 * NJ;  // row stores per wave and tile in the epilogue
     constexpr int NBIAS = GATE ? 2 : 4 * NJ;                       // bias loads per lane and tile (issued at the tile's start)
     extern __shared__ __attribute__((aligned(16))) char rlds[];
@@ -349,7 +350,30 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                 else if constexpr (ACT == LDM_ACT_LRELU) v = v > 0.f ? v : v * slope;
                 return v;
             };
-            if constexpr (GF) {
+            if constexpr (GF && ET == 0) {
+                // ReGLU forward of the fp32 training step: hid = (a + ba) relu(b + bb) AND the two pre-activations, all fp32 [M, ldo]:
+                // three passes of each 32 x 32 piece through the scratch, 16 bytes per lane and store (unet.py:14-15 + what its
+                // autograd keeps); replaces two plain GEMMs and an elementwise pass
+                const int ldo_ = (int)p.ldo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pass = 0; pass < 3; ++pass) {
+                        float *o32 = (float *)(pass == 0 ? p.out : (pass == 1 ? p.out2 : p.out3));
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float av = acc[i][0][e] + b1[0], gt = acc[i][1][e] + b2;
+                            const float v = pass == 0 ? av * fmaxf(gt, 0.f) : (pass == 1 ? av : gt);
+                            const int slot = h | (e & 2) | ((e & 1) << 2) | ((e >> 2) << 3);
+                            *(float *)(scr + slot * 128 + r * 4) = v;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 v = *(const f32x4 *)(scr + (8 * k + rsub) * 128 + cc * 16);
+                            *(f32x4 *)(o32 + (orow0 + i * 32 + 8 * k + rrow) * ldo_ + c_n0 + wn * 32 + cc * 4) = v;
+                        }
+                    }
+            } else if constexpr (GF) {
                 // ReGLU forward of the bf16 training step: hid = (a + ba) relu(b + bb) AND the two pre-activations, all bf16 [M, ldo];
                 // three passes of each 32 x 32 fp32 piece through the scratch, 4 columns (8 bytes) per lane
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -554,8 +578,10 @@ int ldm_gemm_ring_dispatch_f32(const GemmP &p, int groups, bool gate, int amode,
 {
     if (amode != LDM_A_ROWS || p.o_mode != LDM_O_ROWS) return 0;
     if (!gate && p.act != LDM_ACT_NONE && p.act != LDM_ACT_RELU && p.act != LDM_ACT_LRELU) return 0;
-    const int nj = ring_shape(p, groups, gate, false, true);
+    const bool keep_pre = gate && p.out2 != nullptr;                 // ldm_gemm_f32_gate_fwd: hidden + both pre-activations
+    const int nj = ring_shape(p, groups, gate, false, true, keep_pre);
     if (nj == 0) return 0;
+    if (keep_pre) return p.addend ? 0 : ring_launch<0, 2, true, false, false, 3>(p, st);
     if (gate) return p.addend ? 0 : ring_launch<0, 2, true, false>(p, st);
     if (p.addend) return nj == 2 ? ring_launch<0, 2, false, false, true>(p, st) : ring_launch<0, 1, false, false, true>(p, st);
     return nj == 2 ? ring_launch<0, 2, false, false, false>(p, st) : ring_launch<0, 1, false, false, false>(p, st);

@@ -102,6 +102,33 @@ def gemm(a, M, N, K, weights, out, *, lda=None, ldo=None, weights2=None, biases=
     return out
 
 
+def gemm_gate_fwd(a, M, N, K, weights_a, weights_b, hid, a_pre, b_pre, *, biases_a=None, biases_b=None):
+    """ReGLU forward of the fp32 training step: hid = (A Wa^T + ba) * relu(A Wb^T + bb) plus both pre-activations, all fp32 [M, N], in ONE
+    launch where the ring kernel takes the shape; otherwise the three launches it is bit-identical to (two plain GEMMs, gate_fwd)."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.a, d.lda = _dev(a, "a"), K
+    d.M, d.N, d.K = M, N, K
+    d.a_mode, d.o_mode = A_ROWS, O_ROWS
+    nseg = len(weights_a)
+    d.nseg, d.seg_mode, d.seg_len = nseg, SEG_N, N // nseg
+    for s in range(nseg):
+        d.w[s], d.w2[s] = _dev(weights_a[s], "weight a"), _dev(weights_b[s], "weight b")
+        if biases_a is not None and biases_a[s] is not None:
+            d.bias[s] = _dev(biases_a[s], "bias a")
+        if biases_b is not None and biases_b[s] is not None:
+            d.bias2[s] = _dev(biases_b[s], "bias b")
+    d.ldw, d.act = K, ACT_GATE
+    d.out, d.ldo, d.ldadd, d.groups = _dev(hid, "hid"), N, N, 1
+    rc = lib.ldm_gemm_f32_gate_fwd(ctypes.byref(d), _dev(a_pre, "a_pre"), _dev(b_pre, "b_pre"), _stream())
+    if rc == 1:                               # no single-launch instance for this shape
+        gemm(a, M, N, K, weights_a, a_pre, biases=biases_a)
+        gemm(a, M, N, K, weights_b, b_pre, biases=biases_b)
+        return gate_fwd(a_pre, b_pre, hid)
+    _lib.check(rc, "ldm_gemm_f32_gate_fwd")
+    return hid
+
+
 def pointer_table(tensors):
     """Host array of device addresses for gemm(w_table=/bias_table=); keep it alive during the call."""
     arr = (ctypes.c_void_p * len(tensors))()

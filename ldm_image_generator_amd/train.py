@@ -207,10 +207,10 @@ def block_forward(blk, rows, shape, ctx, picks, film, codes, enc_hidden):
     f = regs[0].a.weight.shape[0]
     a_pre = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
     b_pre = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
-    ops.gemm(xf, m, 3 * f, c, [_w2d(r.a.weight) for r in regs], a_pre, biases=[r.a.bias.detach() for r in regs])
-    ops.gemm(xf, m, 3 * f, c, [_w2d(r.b.weight) for r in regs], b_pre, biases=[r.b.bias.detach() for r in regs])
     hid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
-    ops.gate_fwd(a_pre, b_pre, hid)
+    # a(x) * relu(b(x)) of the three ReGLUs with both pre-activations kept for the backward: one launch where the ring kernel takes the shape
+    ops.gemm_gate_fwd(xf, m, 3 * f, c, [_w2d(r.a.weight) for r in regs], [_w2d(r.b.weight) for r in regs], hid, a_pre, b_pre,
+                      biases_a=[r.a.bias.detach() for r in regs], biases_b=[r.b.bias.detach() for r in regs])
     ops.gemm(hid, m, c, 3 * f, [_w2d(r.c.weight) for r in regs], y, biases=[r.c.bias.detach() for r in regs],
              seg_mode=ops.SEG_K, addend=y)
     sv.update(regs=regs, a_pre=a_pre, b_pre=b_pre, hid=hid)

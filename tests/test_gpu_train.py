@@ -306,6 +306,32 @@ def test_training_step_matches_reference_gradients(gpu_device):
     assert rel_l2(net.decoder_last.weight.grad.cpu(), T(g["grad_decoder_last_weight"])) < 1e-4
 
 
+@pytest.mark.parametrize("M,C,ring", [(65536, 256, 2), (4096, 128, 2), (1024, 64, 1), (768, 96, 1)])
+def test_gemm_gate_fwd_equals_three_launches(gpu_device, M, C, ring):
+    """ldm_gemm_f32_gate_fwd (hidden + both pre-activations of three ReGLUs in one launch of the ring kernel's gated instance) ==
+    two plain GEMMs + gate_fwd, bit for bit; shapes the ring kernel does not take fall back to exactly those three launches."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).cuda()
+    wa = [(torch.randn(C, C, generator=g) * C ** -0.5).cuda() for _ in range(3)]
+    wb = [(torch.randn(C, C, generator=g) * C ** -0.5).cuda() for _ in range(3)]
+    ba = [torch.randn(C, generator=g).cuda() for _ in range(3)]
+    bb = [torch.randn(C, generator=g).cuda() for _ in range(3)]
+    ref_a, ref_b, ref_h = (torch.empty(M, 3 * C, device=gpu_device) for _ in range(3))
+    old = ops.gemm_ring(ring)
+    try:
+        ops.gemm(x, M, 3 * C, C, wa, ref_a, biases=ba)
+        ops.gemm(x, M, 3 * C, C, wb, ref_b, biases=bb)
+        ops.gate_fwd(ref_a, ref_b, ref_h)
+        a_pre, b_pre, hid = (torch.full((M, 3 * C), float("nan"), device=gpu_device) for _ in range(3))
+        ops.gemm_gate_fwd(x, M, 3 * C, C, wa, wb, hid, a_pre, b_pre, biases_a=ba, biases_b=bb)
+    finally:
+        ops.gemm_ring(old)
+    assert torch.equal(a_pre, ref_a) and torch.equal(b_pre, ref_b) and torch.equal(hid, ref_h)
+    ref64 = (x.double() @ torch.cat(wa).double().t() + torch.cat(ba).double()) * torch.relu(x.double() @ torch.cat(wb).double().t() + torch.cat(bb).double())
+    assert rel_l2(hid.double().cpu(), ref64.cpu()) < 1e-5
+
+
 def test_training_step_stem_size_2(gpu_device):
     """stem_size = 2: loss and every parameter gradient of one calculate_loss backward vs the reference's autograd (unet_stem2.npz)."""
     from ldm_image_generator_amd.ddpm import DDPM
