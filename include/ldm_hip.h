@@ -130,6 +130,10 @@ int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream);
  * fp32 [M, ldo].  Bit-identical to two plain ldm_gemm_f32 launches + ldm_gate_fwd_f32.  Returns 0 when launched, 1 when no kernel
  * instance takes the shape (nothing was launched: run the three launches instead), negative on error. */
 int ldm_gemm_f32_gate_fwd(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream);
+/* ReGLU backward of the fp32 training step in the epilogue of dh = dY . Wc (d: that plain GEMM, rows in / out, no activation, no addend):
+ * d->out = da = dh * relu(b_pre), db = dh * a_pre * (b_pre > 0), all fp32 [M, ldo]; dh itself is never stored.  Bit-identical to
+ * ldm_gemm_f32 + ldm_gate_bwd_f32.  Returns 0 when launched, 1 when no kernel instance takes the shape, negative on error. */
+int ldm_gemm_f32_gate_bwd(const ldm_gemm_desc *d, const float *a_pre, const float *b_pre, float *db, void *stream);
 int ldm_gemm_variant(int v);
 /* epilogue of the stream schedule for plain-rows outputs: 1 (default) = through LDS, 16 bytes per lane per store;
  * 0 = direct from the MFMA layout, 4 bytes per lane.  Bit-identical results; A/B knob.  Returns the previous setting. */

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ldm_scratch_release": (_I, []),
     "ldm_gemm_f32": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "ldm_gemm_f32_gate_fwd": (_I, [_P, _P, _P, _P]),
+    "ldm_gemm_f32_gate_bwd": (_I, [_P, _P, _P, _P, _P]),
     "ldm_gemm_variant": (_I, [_I]),
     "ldm_gemm_wide_epilogue": (_I, [_I]),
     "ldm_gemm_ring": (_I, [_I]),

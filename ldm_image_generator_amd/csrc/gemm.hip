@@ -332,9 +332,21 @@ extern "C" int ldm_gemm_variant(int v)
     return old;
 }
 
-static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream);
+static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream, float *db = nullptr);
 
 extern "C" int ldm_gemm_f32(const ldm_gemm_desc *d, void *stream) { return gemm_f32_impl(d, nullptr, nullptr, stream); }
+
+// ReGLU backward of the fp32 training step in the epilogue of dh = dY . Wc: d describes that plain GEMM (rows in, rows out [M, ldo], no
+// activation, no addend); its result is NOT stored -- d->out receives da = dh * relu(b_pre), db receives dh * a_pre * (b_pre > 0), all fp32
+// [M, ldo].  Bit-identical to ldm_gemm_f32 + ldm_gate_bwd_f32.  Returns 0 when launched, 1 when no kernel instance takes the shape.
+extern "C" int ldm_gemm_f32_gate_bwd(const ldm_gemm_desc *d, const float *a_pre, const float *b_pre, float *db, void *stream)
+{
+    LDM_REQUIRE(d && a_pre && b_pre && db, "ldm_gemm_f32_gate_bwd: null pointer");
+    LDM_REQUIRE(d->act == LDM_ACT_NONE && !d->addend && d->a_mode == LDM_A_ROWS && d->o_mode == LDM_O_ROWS, "ldm_gemm_f32_gate_bwd: plain rows problem without addend only");
+    LDM_REQUIRE(ldm_aligned16(a_pre) && ldm_aligned16(b_pre) && ldm_aligned16(db) && ldm_aligned16(d->out) && d->ldo % 4 == 0,
+                "ldm_gemm_f32_gate_bwd: operands must be 16-byte addressable");
+    return gemm_f32_impl(d, (float *)a_pre, (float *)b_pre, stream, db);
+}
 
 // ReGLU forward of the fp32 training step in ONE launch: out = (A Wa^T + ba) * relu(A Wb^T + bb) AND a_pre / b_pre (the two
 // pre-activations its backward needs), all fp32 [M, ldo].  d as for ldm_gemm_f32 with act = LDM_ACT_GATE, rows in, rows out, no addend.
@@ -347,7 +359,7 @@ extern "C" int ldm_gemm_f32_gate_fwd(const ldm_gemm_desc *d, float *a_pre, float
     return gemm_f32_impl(d, a_pre, b_pre, stream);
 }
 
-static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream)
+static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, void *stream, float *db)
 {
     LDM_REQUIRE(d != nullptr, "ldm_gemm_f32: null descriptor");
     LDM_REQUIRE(d->a && d->out, "ldm_gemm_f32: null operand");
@@ -420,13 +432,19 @@ static int gemm_f32_impl(const ldm_gemm_desc *d, float *a_pre, float *b_pre, voi
     LDM_REQUIRE(!(gate && d->a_mode == LDM_A_CONV3X3), "ldm_gemm_f32: GATE with conv3x3 unsupported");       // before the profiler opens a record
     void *rec = ldm_prof_begin(LDM_PROF_GEMM, 2.0 * d->M * (double)d->N * d->K * groups * (gate ? 2.0 : 1.0), st,
                                algo_bytes + (a_pre ? 8.0 * o_elems : 0.0));
-    if (a_pre) {                                                  // hidden + both pre-activations: the ring kernel's gated instance or nothing
-        p.out2 = a_pre;
-        p.out3 = b_pre;
-        const int taken = g_variant == 1 ? ldm_gemm_ring_dispatch_f32(p, groups, true, d->a_mode, st) : 0;
+    if (a_pre) {                                                  // fused ReGLU forward / backward: a ring-kernel instance or nothing
+        if (db) {
+            p.in2 = a_pre;
+            p.in3 = b_pre;
+            p.out2 = db;
+        } else {
+            p.out2 = a_pre;
+            p.out3 = b_pre;
+        }
+        const int taken = g_variant == 1 ? ldm_gemm_ring_dispatch_f32(p, groups, db == nullptr, d->a_mode, st) : 0;
         ldm_prof_end(rec, st);
         if (!taken) return 1;
-        LDM_CHECK_LAUNCH("ldm_gemm_f32_gate_fwd");
+        LDM_CHECK_LAUNCH(db ? "ldm_gemm_f32_gate_bwd" : "ldm_gemm_f32_gate_fwd");
         return LDM_OK;
     }
     if (!(d->workspace && splitk_launch(*d, p, gate, st))) launch_any(p, groups, gate, d->a_mode, st);

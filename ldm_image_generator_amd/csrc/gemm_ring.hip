@@ -81,9 +81,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     constexpr int BN = GATE ? 128 : 128 * NJ;                      // output columns per tile
     constexpr int RPW = 2 + NJ;                                    // LDS-DMA instructions per wave and step (2 x A, NJ x W)
     constexpr int NM = (ET ? 1 : 4) * 4 * NJ;                      // MFMAs of one slice
-    static_assert(!GF || (GATE && !OBF && !ADD), "gate forward with saved pre-activations: a gated instance");
-    static_assert(!GF || ET == 1 || GF == 3, "fp32: hidden + both pre-activations (the training forward) or the plain gated instance");
-    constexpr int NSTORE = GF ? 16 * GF : (OBF || GATE) ? 16 : 16 * NJ;  // row stores per wave and tile in the epilogue
+    // GF == 4 (fp32, plain NJ == 2 instance): the ReGLU BACKWARD in the epilogue -- the GEMM result is dh; da = dh relu(b), db = dh a (b > 0)
+    // with a = p.in2, b = p.in3 (fp32 [M, ldo] like the two outputs p.out, p.out2); dh never reaches HBM
+    constexpr bool GBW = GF == 4;
+    static_assert(!GF || GBW || (GATE && !OBF && !ADD), "gate forward with saved pre-activations: a gated instance");
+    static_assert(!GF || ET == 1 || GF == 3 || GBW, "fp32: hidden + both pre-activations (the training forward) or the plain gated instance");
+    static_assert(!GBW || (ET == 0 && NJ == 2 && !GATE && !OBF && !ADD), "gate backward: the plain fp32 256 x 256 instance");
+    constexpr int NSTORE = GBW ? 32 * NJ : GF ? 16 * GF : (OBF || GATE) ? 16 : 16 * NJ;  // row stores per wave and tile in the epilogue
     constexpr int NBIAS = GATE ? 2 : 4 * NJ;                       // bias loads per lane and tile (issued at the tile's start)
     extern __shared__ __attribute__((aligned(16))) char rlds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -284,7 +288,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
             // (all workgroups finish their equally long tiles together: 32 k cycles per tile before this).
             // The tile's NBIAS bias loads are younger than that DMA in the same three steps.
             if (kt < 3 && nk >= 3) {
-                if (c_tile > 0) ring_wait<2 * RPW + NSTORE + NBIAS>();
+                // (vmcnt is a 6-bit counter: a larger count is clamped, which only makes the wait stricter)
+                if (c_tile > 0) ring_wait<(2 * RPW + NSTORE + NBIAS < 63 ? 2 * RPW + NSTORE + NBIAS : 63)>();
                 else ring_wait<2 * RPW + NBIAS>();
             } else {
                 ring_wait<2 * RPW>();
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                 else if constexpr (ACT == LDM_ACT_LRELU) v = v > 0.f ? v : v * slope;
                 return v;
             };
-            if constexpr (GF && ET == 0) {
+            if constexpr (GF == 3 && ET == 0) {
                 // ReGLU forward of the fp32 training step: hid = (a + ba) relu(b + bb) AND the two pre-activations, all fp32 [M, ldo]:
                 // three passes of each 32 x 32 piece through the scratch, 16 bytes per lane and store (unet.py:14-15 + what its
                 // autograd keeps); replaces two plain GEMMs and an elementwise pass
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                             *(f32x4 *)(o32 + (orow0 + i * 32 + 8 * k + rrow) * ldo_ + c_n0 + wn * 32 + cc * 4) = v;
                         }
                     }
-            } else if constexpr (GF) {
+            } else if constexpr (GF && !GBW) {
                 // ReGLU forward of the bf16 training step: hid = (a + ba) relu(b + bb) AND the two pre-activations, all bf16 [M, ldo];
                 // three passes of each 32 x 32 fp32 piece through the scratch, 4 columns (8 bytes) per lane
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -448,6 +453,18 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                 } else if constexpr (ADD) {
                     load_add(0);
                 }
+                // gate backward: the pre-activations of half fragment hh + 1 are loaded before half fragment hh is stored (as the addend)
+                f32x4 ga[2][2], gb[2][2];
+                auto load_gate = [&](int hh) {
+                    const int f = hh >> 1, kh = hh & 1;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const long long at = (orow0 + (f / NJO) * 32 + 8 * (2 * kh + k) + rrow) * ldo_ + col_of(f);
+                        ga[hh & 1][k] = *(const f32x4 *)((const float *)p.in2 + at);
+                        gb[hh & 1][k] = *(const f32x4 *)((const float *)p.in3 + at);
+                    }
+                };
+                if constexpr (GBW) load_gate(0);
 #pragma unroll
                 for (int f = 0; f < NFR; ++f) {
                     const int i = f / NJO, j = f % NJO;
@@ -471,8 +488,26 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) v[k][q] += ad[ADD_ALL ? hh : (hh & 1)][k][q];
                         }
+                        if constexpr (GBW) {
+                            if (hh + 1 < 2 * NFR) load_gate(hh + 1);
+                            float *o2 = (float *)p.out2;
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) *(f32x4 *)(o32 + (orow0 + i * 32 + 8 * (2 * kh + k) + rrow) * ldo_ + col_of(f)) = v[k];
+                            for (int k = 0; k < 2; ++k) {
+                                f32x4 oa, ob;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float g = v[k][q], av = ga[hh & 1][k][q], bv = gb[hh & 1][k][q];
+                                    oa[q] = g * fmaxf(bv, 0.f);                      // exactly ldm_gate_bwd_f32's arithmetic
+                                    ob[q] = bv > 0.f ? g * av : 0.f;
+                                }
+                                const long long at = (orow0 + i * 32 + 8 * (2 * kh + k) + rrow) * ldo_ + col_of(f);
+                                *(f32x4 *)(o32 + at) = oa;
+                                *(f32x4 *)(o2 + at) = ob;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) *(f32x4 *)(o32 + (orow0 + i * 32 + 8 * (2 * kh + k) + rrow) * ldo_ + col_of(f)) = v[k];
+                        }
                     }
                 }
             }
@@ -578,6 +613,13 @@ int ldm_gemm_ring_dispatch_f32(const GemmP &p, int groups, bool gate, int amode,
 {
     if (amode != LDM_A_ROWS || p.o_mode != LDM_O_ROWS) return 0;
     if (!gate && p.act != LDM_ACT_NONE && p.act != LDM_ACT_RELU && p.act != LDM_ACT_LRELU) return 0;
+    if (!gate && p.in2 && p.in3 && p.out2) {                         // ldm_gemm_f32_gate_bwd: da, db out of dh = dy . Wc in the epilogue
+        GemmP q = p;
+        q.out2 = nullptr;
+        q.in2 = q.in3 = nullptr;
+        if (p.addend || p.act != LDM_ACT_NONE || ring_shape(q, groups, false, false, true) != 2) return 0;
+        return ring_launch<0, 2, false, false, false, 4>(p, st);
+    }
     const bool keep_pre = gate && p.out2 != nullptr;                 // ldm_gemm_f32_gate_fwd: hidden + both pre-activations
     const int nj = ring_shape(p, groups, gate, false, true, keep_pre);
     if (nj == 0) return 0;

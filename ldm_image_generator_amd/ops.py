@@ -129,6 +129,31 @@ def gemm_gate_fwd(a, M, N, K, weights_a, weights_b, hid, a_pre, b_pre, *, biases
     return hid
 
 
+def gemm_gate_bwd(dy, M, N, K, weights_t, a_pre, b_pre, da, db):
+    """ReGLU backward of the fp32 training step: dh = dy . Wc (weights_t: the transposed c-weights as N-segments [N / nseg, K]) with
+    da = dh * relu(b_pre), db = dh * a_pre * (b_pre > 0) formed in the GEMM's epilogue (dh never reaches HBM) where the ring kernel takes
+    the shape; otherwise the two launches it is bit-identical to (plain GEMM into a temporary, gate_bwd)."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.a, d.lda = _dev(dy, "dy"), K
+    d.M, d.N, d.K = M, N, K
+    d.a_mode, d.o_mode = A_ROWS, O_ROWS
+    nseg = len(weights_t)
+    d.nseg, d.seg_mode, d.seg_len = nseg, SEG_N, N // nseg
+    for s in range(nseg):
+        d.w[s] = _dev(weights_t[s], "weight")
+    d.ldw, d.act = K, ACT_NONE
+    d.out, d.ldo, d.ldadd, d.groups = _dev(da, "da"), N, N, 1
+    rc = lib.ldm_gemm_f32_gate_bwd(ctypes.byref(d), _dev(a_pre, "a_pre"), _dev(b_pre, "b_pre"), _dev(db, "db"), _stream())
+    if rc == 1:
+        dh = torch.empty(M, N, device=dy.device, dtype=torch.float32)
+        gemm(dy, M, N, K, weights_t, dh)
+        gate_bwd(dh, a_pre, b_pre, da, db)
+        return da, db
+    _lib.check(rc, "ldm_gemm_f32_gate_bwd")
+    return da, db
+
+
 def pointer_table(tensors):
     """Host array of device addresses for gemm(w_table=/bias_table=); keep it alive during the call."""
     arr = (ctypes.c_void_p * len(tensors))()

@@ -228,11 +228,10 @@ def block_backward(sv, dy, ctx, grads):
     # ---- RandomMoE: y += sum_e c_e(a_e(xf) * relu(b_e(xf))) ----------------------------------------------
     dwc = grad_weight_rows(dy_r, _Rows(sv["hid"]), m)               # [C, 3F]
     bias_dy = dy_r.colsum()
-    dhid = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
-    ops.gemm(dy, m, 3 * f, c, [WT.get(_w2d(r.c.weight), r.c.weight) for r in regs], dhid)
-    da = torch.empty_like(dhid)
-    db = torch.empty_like(dhid)
-    ops.gate_bwd(dhid, sv["a_pre"], sv["b_pre"], da, db)
+    da = torch.empty(m, 3 * f, device=dev, dtype=torch.float32)
+    db = torch.empty_like(da)
+    # dhid = dy . Wc with the gate's backward in the epilogue (dhid never reaches HBM) where the ring kernel takes the shape
+    ops.gemm_gate_bwd(dy, m, 3 * f, c, [WT.get(_w2d(r.c.weight), r.c.weight) for r in regs], sv["a_pre"], sv["b_pre"], da, db)
     dxf = torch.empty(m, c, device=dev, dtype=torch.float32)
     ops.gemm(da, m, c, 3 * f, [WT.get(_w2d(r.a.weight), r.a.weight) for r in regs], dxf, seg_mode=ops.SEG_K)
     ops.gemm(db, m, c, 3 * f, [WT.get(_w2d(r.b.weight), r.b.weight) for r in regs], dxf, seg_mode=ops.SEG_K, addend=dxf)

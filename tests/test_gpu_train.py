@@ -332,6 +332,27 @@ def test_gemm_gate_fwd_equals_three_launches(gpu_device, M, C, ring):
     assert rel_l2(hid.double().cpu(), ref64.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("M,C,ring", [(65536, 256, 2), (4096, 128, 2), (1024, 64, 1)])
+def test_gemm_gate_bwd_equals_two_launches(gpu_device, M, C, ring):
+    """ldm_gemm_f32_gate_bwd (da, db formed in the epilogue of dh = dy . Wc) == plain GEMM + gate_bwd, bit for bit."""
+    from ldm_image_generator_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * C)
+    dy = torch.randn(M, C, generator=g).cuda()
+    wt = [(torch.randn(C, C, generator=g) * C ** -0.5).cuda() for _ in range(3)]          # transposed c-weights [F, C] per expert
+    a_pre, b_pre = torch.randn(M, 3 * C, generator=g).cuda(), torch.randn(M, 3 * C, generator=g).cuda()
+    old = ops.gemm_ring(ring)
+    try:
+        dh = torch.empty(M, 3 * C, device=gpu_device)
+        ops.gemm(dy, M, 3 * C, C, wt, dh)
+        ref_a, ref_b = torch.empty_like(dh), torch.empty_like(dh)
+        ops.gate_bwd(dh, a_pre, b_pre, ref_a, ref_b)
+        da, db = torch.full_like(dh, float("nan")), torch.full_like(dh, float("nan"))
+        ops.gemm_gate_bwd(dy, M, 3 * C, C, wt, a_pre, b_pre, da, db)
+    finally:
+        ops.gemm_ring(old)
+    assert torch.equal(da, ref_a) and torch.equal(db, ref_b)
+
+
 def test_training_step_stem_size_2(gpu_device):
     """stem_size = 2: loss and every parameter gradient of one calculate_loss backward vs the reference's autograd (unet_stem2.npz)."""
     from ldm_image_generator_amd.ddpm import DDPM
