@@ -171,3 +171,23 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_tn_split_counts_fill_one_round_with_whole_splits():
+    """ops.tn_splits_one_round (host logic of the dense 3x3 weight gradient): tiles x splits never exceeds the 512 workgroup slots, every
+    split -- the last, shorter one included -- holds at least 32 rows, multiples of 8 are preferred when they cost < 15 % of the slots."""
+    from ldm_image_generator_amd.ops import tn_splits_one_round
+    for tiles in (1, 3, 5, 9, 12, 36, 48, 144, 600):
+        for m in (128, 4096, 6272, 131072, 524288, 8 * 250 * 250 // 32 * 32):
+            s = tn_splits_one_round(tiles, m)
+            assert s >= 1 and (tiles * s <= 512 or s == 1), (tiles, m, s)
+            ms = ((m + s - 1) // s + 31) // 32 * 32
+            assert (s - 1) * ms < m and m - (s - 1) * ms >= 32, (tiles, m, s, ms)
+    assert tn_splits_one_round(9, 131072) == 56 and tn_splits_one_round(5, 524288) == 96 and tn_splits_one_round(36, 32768) == 14
+
+
+def test_conv3x3_wgrad_plane_height_is_the_tile_height_the_kernel_picks():
+    """ldm_conv3x3_wgrad_npad (host arithmetic only): 32 / 64-row tiles for Cout <= 32 / 64, multiples of 128 above."""
+    from ldm_image_generator_amd import _lib
+    lib = _lib.load()
+    assert [lib.ldm_conv3x3_wgrad_npad(c) for c in (4, 32, 33, 48, 64, 65, 128, 192, 512)] == [32, 32, 64, 64, 64, 128, 128, 256, 512]
