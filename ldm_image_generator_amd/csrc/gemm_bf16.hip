@@ -142,12 +142,14 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 
 // LDS-DMA from inline asm (16 bytes per lane, destination = wave-uniform LDS byte address + lane * 16).  M0 carries the
 // destination and is compiler-reserved: saved and restored inside the one statement that uses it.
-__device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_dst)
+// Source = wave-uniform base (SGPR pair) + this lane's 32-bit byte offset, a loop invariant: no 64-bit vector address arithmetic per
+// instruction (the first form took the whole address in a VGPR pair: a 64-bit multiply-add per DMA instruction and lane).
+__device__ __forceinline__ void glds16_asm(const char *base, int off, unsigned lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(off), "s"(base), "s"(lds_dst)
                  : "memory");
 }
 
@@ -192,17 +194,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const TnP16 p)
     // waits below alone (with the builtin it put s_waitcnt vmcnt(0) in front of the first transposing read of every stage).
     const int drow = lane >> 4, dchunk = lane & 15;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short *)lds16;
+    int a_voff[2], b_voff[2];                                         // byte offsets of this lane's chunks inside a stage's rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * (4 * i + wave) + drow;
+        const int csrc = (dchunk ^ tn_swz(row)) * 8;
+        a_voff[i] = (int)((row * p.lda + n0 + csrc) * 2);
+        b_voff[i] = (int)((row * p.ldb + k0 + csrc) * 2);
+    }
     auto issue = [&](int step) {
         const unsigned dst0 = lds_base + (unsigned)(((step % NS) * STAGE + wave * 512) * 2);       // bytes; + i * 4096 + subtile * 8192
         const long long mbase = row0 + (long long)step * TBR;
+        const char *abase = (const char *)(p.a + mbase * p.lda), *bbase = (const char *)(p.b + mbase * p.ldb);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = 4 * (4 * i + wave) + drow;
-            const int csrc = (dchunk ^ tn_swz(row)) * 8;
-            glds16_asm(p.a + (mbase + row) * p.lda + n0 + csrc, __builtin_amdgcn_readfirstlane(dst0 + i * 4096));
+            glds16_asm(abase, a_voff[i], __builtin_amdgcn_readfirstlane(dst0 + i * 4096));
 #pragma unroll
             for (int j = 0; j < KT; ++j)
-                glds16_asm(p.b + (mbase + row) * p.ldb + k0 + j * TBT + csrc, __builtin_amdgcn_readfirstlane(dst0 + i * 4096 + (1 + j) * TSUB * 2));
+                glds16_asm(bbase + j * TBT * 2, b_voff[i], __builtin_amdgcn_readfirstlane(dst0 + i * 4096 + (1 + j) * TSUB * 2));
         }
     };
 
@@ -322,15 +331,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_ring_kernel(const TnP16 p
     // instruction pieces 4 w .. 4 w + 3 (sub-tile = piece >> 3, rows 4 (piece & 7) .. + 3)
     const int drow = lane >> 4, dchunk = lane & 15;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short *)lds16;
+    int voff[PW];                                                     // byte offset of this lane's chunk from the stage's first row of its operand
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int piece = 4 * wave + i;
+        const int sub = piece >> 3, row = 4 * (piece & 7) + drow;
+        const int csrc = (dchunk ^ tn_swz(row)) * 8;
+        voff[i] = (int)((sub < 2 ? row * p.lda + n0 + sub * TBT + csrc : row * p.ldb + k0 + (sub - 2) * TBT + csrc) * 2);
+    }
     auto issue = [&](int step) {
         const long long mbase = row0 + (long long)step * TBR;
+        const char *abase = (const char *)(p.a + mbase * p.lda), *bbase = (const char *)(p.b + mbase * p.ldb);
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int piece = 4 * wave + i;
-            const int sub = piece >> 3, row = 4 * (piece & 7) + drow;
-            const int csrc = (dchunk ^ tn_swz(row)) * 8;
-            const unsigned short *src = sub < 2 ? p.a + (mbase + row) * p.lda + n0 + sub * TBT + csrc : p.b + (mbase + row) * p.ldb + k0 + (sub - 2) * TBT + csrc;
-            glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((step % NS) * STAGE + sub * TSUB + 4 * (piece & 7) * TBT) * 2)));
+            const int sub = piece >> 3;                               // wave-uniform: waves 0-3 move A, 4-7 move B
+            glds16_asm(sub < 2 ? abase : bbase, voff[i], __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((step % NS) * STAGE + sub * TSUB + 4 * (piece & 7) * TBT) * 2)));
         }
     };
 
@@ -433,6 +449,7 @@ extern "C" int ldm_gemm_tn_bf16(const void *a, long long lda, const void *b, lon
     LDM_REQUIRE(splits >= 1 && M % splits == 0 && (M / splits) % 64 == 0, "ldm_gemm_tn_bf16: M=%d must split into %d runs of a multiple of 64 rows", M, splits);
     LDM_REQUIRE(lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldm_aligned16(a) && ldm_aligned16(b),
                 "ldm_gemm_tn_bf16: operands must be 16-byte addressable (lda=%lld ldb=%lld)", lda, ldb);
+    LDM_REQUIRE(lda < (1ll << 24) && ldb < (1ll << 24), "ldm_gemm_tn_bf16: row strides must stay below 2^24 elements (32-bit lane offsets)");
     TnP16 p{};
     p.a = (const unsigned short *)a; p.b = (const unsigned short *)b; p.out = out; p.colsum = colsum_a; p.lda = lda; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.ms = M / splits; p.splits = splits; p.ntn = N / TBT;

@@ -42,12 +42,16 @@ int g_ring = 1;                              // 0 off, 1 auto (large problems), 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void ring_glds16(const void *gsrc, unsigned lds_dst)
+// one LDS-DMA instruction: 64 lanes x 16 bytes from base + off (base: wave-uniform, in SGPRs; off: this lane's 32-bit byte offset, a loop
+// invariant) to LDS at lds_dst + 16 lane.  The scalar-base form needs no 64-bit vector add per instruction (the earlier form took the
+// whole address in a VGPR pair: two VALU instructions per DMA instruction, eight per wave and step, in a loop whose issue slots are
+// what the bf16 instances run out of)
+__device__ __forceinline__ void ring_glds16(const char *base, int off, unsigned lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(off), "s"(base), "s"(lds_dst)
                  : "memory");
 }
 
@@ -148,10 +152,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     };
     // part 0 .. RPW - 1: A rows 0-15, W rows 0-15, A rows 16-31 (, W rows 16-31) of this wave
     auto issue_part = [&](int part) {
-        if (part == 0) ring_glds16(ld_a + a_off[0], __builtin_amdgcn_readfirstlane(ld_dst + wave * 2048));
-        else if (part == 2) ring_glds16(ld_a + a_off[1], __builtin_amdgcn_readfirstlane(ld_dst + wave * 2048 + 1024));
-        else if (part == 1) ring_glds16(ld_w + w_off[0], __builtin_amdgcn_readfirstlane(ld_dst + 16384 + wave * 1024 * NJ));
-        else if (NJ == 2) ring_glds16(ld_w + w_off[NJ - 1], __builtin_amdgcn_readfirstlane(ld_dst + 16384 + wave * 1024 * NJ + 1024));
+        if (part == 0) ring_glds16(ld_a, a_off[0], __builtin_amdgcn_readfirstlane(ld_dst + wave * 2048));
+        else if (part == 2) ring_glds16(ld_a, a_off[1], __builtin_amdgcn_readfirstlane(ld_dst + wave * 2048 + 1024));
+        else if (part == 1) ring_glds16(ld_w, w_off[0], __builtin_amdgcn_readfirstlane(ld_dst + 16384 + wave * 1024 * NJ));
+        else if (NJ == 2) ring_glds16(ld_w, w_off[NJ - 1], __builtin_amdgcn_readfirstlane(ld_dst + 16384 + wave * 1024 * NJ + 1024));
     };
     auto issue_advance = [&](bool live) {
         ++l_step;
