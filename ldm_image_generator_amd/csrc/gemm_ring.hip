@@ -46,6 +46,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // invariant) to LDS at lds_dst + 16 lane.  The scalar-base form needs no 64-bit vector add per instruction (the earlier form took the
 // whole address in a VGPR pair: two VALU instructions per DMA instruction, eight per wave and step, in a loop whose issue slots are
 // what the bf16 instances run out of)
+// (the address-in-a-VGPR-pair form: kept for the bf16 instances, where the scalar-base form measured 0.8 % SLOWER over a sampling pass --
+// 446.9 vs 443.5 ms, two alternations on one box -- while it is worth 3 % to the fp32 instances)
+__device__ __forceinline__ void ring_glds16v(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 __device__ __forceinline__ void ring_glds16(const char *base, int off, unsigned lds_dst)
 {
     unsigned keep;
@@ -152,10 +163,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
     };
     // part 0 .. RPW - 1: A rows 0-15, W rows 0-15, A rows 16-31 (, W rows 16-31) of this wave
     auto issue_part = [&](int part) {
-        if (part == 0) ring_glds16(ld_a, a_off[0], __builtin_amdgcn_readfirstlane(ld_dst + wave * 2048));
-        else if (part == 2) ring_glds16(ld_a, a_off[1], __builtin_amdgcn_readfirstlane(ld_dst + wave * 2048 + 1024));
-        else if (part == 1) ring_glds16(ld_w, w_off[0], __builtin_amdgcn_readfirstlane(ld_dst + 16384 + wave * 1024 * NJ));
-        else if (NJ == 2) ring_glds16(ld_w, w_off[NJ - 1], __builtin_amdgcn_readfirstlane(ld_dst + 16384 + wave * 1024 * NJ + 1024));
+        const char *src = (part & 1) ? ld_w : ld_a;
+        const int off = part == 0 ? a_off[0] : part == 2 ? a_off[1] : part == 1 ? w_off[0] : w_off[NJ - 1];
+        const unsigned dst = part == 0 ? ld_dst + wave * 2048 : part == 2 ? ld_dst + wave * 2048 + 1024
+                           : part == 1 ? ld_dst + 16384 + wave * 1024 * NJ : ld_dst + 16384 + wave * 1024 * NJ + 1024;
+        if (part == 3 && NJ != 2) return;
+        if constexpr (ET == 0) ring_glds16(src, off, __builtin_amdgcn_readfirstlane(dst));
+        else ring_glds16v(src + off, __builtin_amdgcn_readfirstlane(dst));
     };
     auto issue_advance = [&](bool live) {
         ++l_step;
