@@ -472,15 +472,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                     load_add(0);
                 }
                 // gate backward: the pre-activations of half fragment hh + 1 are loaded before half fragment hh is stored (as the addend)
-                f32x4 ga[2][2], gb[2][2];
-                auto load_gate = [&](int hh) {
-                    const int f = hh >> 1, kh = hh & 1;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const long long at = (orow0 + (f / NJO) * 32 + 8 * (2 * kh + k) + rrow) * ldo_ + col_of(f);
-                        ga[hh & 1][k] = *(const f32x4 *)((const float *)p.in2 + at);
-                        gb[hh & 1][k] = *(const f32x4 *)((const float *)p.in3 + at);
-                    }
+                // (one 8-row piece ahead: half a fragment ahead -- 32 registers of a and b -- spilled beside the 128 accumulators)
+                f32x4 ga[2], gb[2];
+                auto load_gate = [&](int qk) {                // piece qk = 4 f + 2 kh + k
+                    const int f = qk >> 2;
+                    const long long at = (orow0 + (f / NJO) * 32 + 8 * (qk & 3) + rrow) * ldo_ + col_of(f);
+                    ga[qk & 1] = *(const f32x4 *)((const float *)p.in2 + at);
+                    gb[qk & 1] = *(const f32x4 *)((const float *)p.in3 + at);
                 };
                 if constexpr (GBW) load_gate(0);
 #pragma unroll
@@ -507,14 +505,15 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmP p, int nt
                                 for (int q = 0; q < 4; ++q) v[k][q] += ad[ADD_ALL ? hh : (hh & 1)][k][q];
                         }
                         if constexpr (GBW) {
-                            if (hh + 1 < 2 * NFR) load_gate(hh + 1);
                             float *o2 = (float *)p.out2;
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
+                                const int qk = 2 * hh + k;
+                                if (qk + 1 < 4 * NFR) load_gate(qk + 1);
                                 f32x4 oa, ob;
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    const float g = v[k][q], av = ga[hh & 1][k][q], bv = gb[hh & 1][k][q];
+                                    const float g = v[k][q], av = ga[qk & 1][q], bv = gb[qk & 1][q];
                                     oa[q] = g * fmaxf(bv, 0.f);                      // exactly ldm_gate_bwd_f32's arithmetic
                                     ob[q] = bv > 0.f ? g * av : 0.f;
                                 }
