@@ -327,7 +327,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, bool OBF, int ACT, bool SCAT = false>
+// GBW: the ReGLU backward in this epilogue (bf16 rows out, p.in2 / p.in3 / p.out2 set) -- a compile-time flag since round 3: as a
+// run-time one its a / b buffers sat in every bf16-output instance and made the hot ones spill registers in their K loop
+template <int WM, int WN, int TM, int TN, bool GATE, bool OBF, int ACT, bool SCAT = false, bool GBW = false>
 __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int n0, int g, int wm, int wn,
                                                    const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre,
                                                    const WideLane<TN> &wl, float *scratch /* stage base + wave * 256 */)
@@ -357,7 +359,8 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
     }
     // passes over the tile: 1, or 3 for the gate forward that also saves its pre-activations (hid, a, b)
     const int npass = (GATE && OBF && p.out2 != nullptr) ? 3 : 1;
-    const bool gate_bwd = !GATE && OBF && p.in2 != nullptr;
+    static_assert(!GBW || (!GATE && OBF && !SCAT && ACT == LDM_ACT_NONE), "gate backward: plain bf16-output instance without activation");
+    constexpr bool gate_bwd = GBW;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
         unsigned short *ob16 = pass == 0 ? obase16 : (unsigned short *)(pass == 1 ? p.out2 : p.out3) + oelem;
@@ -485,11 +488,13 @@ __device__ __forceinline__ void gemm_epilogue_wide_act(const GemmP &p, f32x16 (&
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, bool OBF = false, bool SCAT = false>
+template <int WM, int WN, int TM, int TN, bool GATE, bool OBF = false, bool SCAT = false, bool GBW = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmP &p, f32x16 (&acc)[GATE ? 2 : 1][TM][TN], int m0, int n0, int g, int wm, int wn,
                                                    const EpiCols<TN> &c, const float (&pre)[TM][TN][16], bool use_pre, const WideLane<TN> &wl, float *scratch)
 {
-    if constexpr (SCAT) {
+    if constexpr (GBW) {
+        gemm_epilogue_wide_act<WM, WN, TM, TN, false, true, LDM_ACT_NONE, false, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);
+    } else if constexpr (SCAT) {
         if (p.act == LDM_ACT_RELU) gemm_epilogue_wide_act<WM, WN, TM, TN, false, false, LDM_ACT_RELU, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);
         else if (p.act == LDM_ACT_LRELU) gemm_epilogue_wide_act<WM, WN, TM, TN, false, false, LDM_ACT_LRELU, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);
         else gemm_epilogue_wide_act<WM, WN, TM, TN, false, false, LDM_ACT_NONE, true>(p, acc, m0, n0, g, wm, wn, c, pre, false, wl, scratch);

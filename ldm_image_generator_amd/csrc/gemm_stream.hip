@@ -86,7 +86,7 @@ __device__ __forceinline__ void mfma6(const Split3 &a, const Split3 &b, f32x16 &
 // ET = 1: both operands are bf16 (rows of 128 B = 64 k), one v_mfma_f32_32x32x16_bf16 per fragment pair; the loader, the LDS
 // ring and the swizzle are unchanged because they only ever move 16-byte chunks of 128-byte rows -- the host passes K, lda,
 // ldw and the group strides in units of 4 bytes (two bf16).  OBF: the (wide) epilogue rounds the result to bf16 (RNE).
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false, bool SCAT = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false, bool SCAT = false, bool GBW = false>
 __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int ntm, int ntn, int total_tiles)
 {
     static_assert(ET == 0 || SPLIT == 0, "bf16 operands: no split consumer");
@@ -415,14 +415,14 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmP p, int 
             mma(fa1, fb1);
         }
         if constexpr (WIDE)      // scratch: this wave's slices of the stage the tile's last step has just released
-            gemm_epilogue_wide<WM, WN, TM, TN, GATE, OBF, SCAT>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
+            gemm_epilogue_wide<WM, WN, TM, TN, GATE, OBF, SCAT, GBW>(p, acc, c_m0, c_n0, c_g, wm, wn, cols, pre, use_pre, wl, lds + (s & 1) * STAGE + wave * 256);
         else
             gemm_epilogue<WM, WN, TM, TN, GATE>(p, acc, c_m0, wm, h, cols, pre, use_pre);
         ++s;
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false, bool SCAT = false>
+template <int WM, int WN, int TM, int TN, bool GATE, int AMODE, int SPLIT = 0, bool WIDE = false, int ET = 0, bool OBF = false, bool SCAT = false, bool GBW = false>
 int launch_stream(const GemmP &p, int groups, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -430,7 +430,7 @@ int launch_stream(const GemmP &p, int groups, hipStream_t st)
     constexpr size_t smem = (size_t)NS * (BM + NB) * 32 * sizeof(float);
     static LdmLdsOptIn opt_in;
     static std::atomic<int> per_cu_cache{0};
-    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE, ET, OBF, SCAT>;
+    auto kern = gemm_stream_kernel<WM, WN, TM, TN, GATE, AMODE, SPLIT, WIDE, ET, OBF, SCAT, GBW>;
     (void)opt_in((const void *)kern, smem);
     int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
@@ -532,6 +532,12 @@ int ldm_gemm_stream_dispatch_bf16(const GemmP &p, int groups, bool out_bf16, hip
     const bool big = unit % 128 == 0 && (long long)((p.M + 127) / 128) * (p.N / 128) * groups >= 512;
     if (out_bf16) {
         if (!p.wide_ok) return 0;
+        if (p.in2) {                     // ReGLU backward in the epilogue (ldm_gemm_bf16_gate_bwd): its own instances
+            if (p.act != LDM_ACT_NONE) return 0;
+            if (big) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, 0, true, 1, true, false, true>(p, groups, st);
+            if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, true, 1, true, false, true>(p, groups, st);
+            return 0;
+        }
         if (big) return launch_stream<2, 2, 2, 2, false, LDM_A_ROWS, 0, true, 1, true>(p, groups, st);
         if (unit % 64 == 0) return launch_stream<2, 2, 2, 1, false, LDM_A_ROWS, 0, true, 1, true>(p, groups, st);
         return 0;

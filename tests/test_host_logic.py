@@ -191,3 +191,29 @@ def test_conv3x3_wgrad_plane_height_is_the_tile_height_the_kernel_picks():
     from ldm_image_generator_amd import _lib
     lib = _lib.load()
     assert [lib.ldm_conv3x3_wgrad_npad(c) for c in (4, 32, 33, 48, 64, 65, 128, 192, 512)] == [32, 32, 64, 64, 64, 128, 128, 256, 512]
+
+
+def test_no_kernel_spills_vector_registers():
+    """Every kernel's register report (written by build.py beside its object, in the build container) shows zero VGPR spills."""
+    import glob
+    import re
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldm_image_generator_amd", "build")
+    reports = glob.glob(os.path.join(here, "*.usage"))
+    if not reports:
+        pytest.skip("no register reports (objects were not compiled by this checkout's build.py)")
+    bad = []
+    for rep in reports:
+        name = None
+        for line in open(rep):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"VGPRs Spill: (\d+)", line)
+            if m and int(m.group(1)) > 0:
+                # known and off the default paths: the stream kernel's opt-in split-schedule instances (SPLIT != 0, ldm_gemm_variant(2)) and
+                # its direct-epilogue instances (WIDE = false: outputs that are not 16-byte addressable)
+                t = re.search(r"gemm_stream_kernelILi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi\d+ELi(\d+)ELb([01])E", name or "")
+                if t and (t.group(1) != "0" or t.group(2) == "0"):
+                    continue
+                bad.append((os.path.basename(rep), name, int(m.group(1))))
+    assert not bad, bad
